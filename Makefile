@@ -1,0 +1,40 @@
+# Builds the product library (HIP, gfx950 only) and, through oracle/Makefile, the test oracle.
+#
+#   make lib      -> cuda-pathtracer_amd/libptmi.so
+#   make oracle   -> oracle/libpt_oracle.so (+ oracle/_ref/*.so where /root/reference exists)
+#   make examples -> examples/pt_headless
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+PKG      := cuda-pathtracer_amd
+CSRC     := $(PKG)/csrc
+# -ffp-contract=off: the trace loop is bit-reproducible against the host oracle only without
+# fused multiply-add; division and sqrt stay IEEE (hipcc's default
+# -fhip-fp32-correctly-rounded-divide-sqrt is left on), denormals are kept.
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+            -fhip-fp32-correctly-rounded-divide-sqrt -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+
+SRCS := $(CSRC)/pt_kernels.hip $(CSRC)/pt_api.cpp $(CSRC)/pt_scene.cpp
+HDRS := include/ptmi.h $(CSRC)/pt_kernels.hpp $(CSRC)/pt_device.hpp
+
+all: lib oracle
+
+lib: $(PKG)/libptmi.so
+
+$(PKG)/libptmi.so: $(SRCS) $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
+
+oracle:
+	$(MAKE) -C oracle all
+	if [ -d /root/reference ]; then $(MAKE) -C oracle ref; fi
+
+examples: examples/pt_headless
+
+examples/pt_headless: examples/main.cpp $(PKG)/host/pathtracer.hpp $(PKG)/libptmi.so
+	$(HIPCC) -O2 -std=c++17 -ffp-contract=off -Iinclude -I$(PKG)/host -o $@ examples/main.cpp \
+	    -L$(PKG) -lptmi -Wl,-rpath,'$$ORIGIN/../$(PKG)'
+
+clean:
+	rm -f $(PKG)/libptmi.so examples/pt_headless
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle examples clean

@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload demo1080|synth10k|mixed16]
+
+A "step" is one full render of the workload: every pixel's camera rays, nearest-hit scans,
+BSDF sampling and accumulation for all of the workload's iterations (one pt_run_n launch).
+The metric is path-bounces per second: the number of Intersect calls (primary rays included,
+scene.h:71-94), counted exactly by the kernel, divided by wall time with the frame buffer
+resident in HBM.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): sample-range split -- every
+rank renders the same frame for its own block of iterations into a SUM buffer (per-GPU work
+fixed: weak scaling) and one RCCL reduce of the accumulation buffers ends the step.
+
+Adds to the JSON line:
+  roofline      FP32 vector-ALU roofline of the render kernel: algorithmic flops per launch
+                ((17*N_spheres + 121) per Intersect call) / HIP-event duration of the launch
+  cpu_baseline  the CPU oracle (a C port of the reference's trace loop, pinned bit-exactly
+                to the reference's host build) on the host's cores, bounded sample, rank 0, N=1
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs[1], configs[3], configs[4]
+WORKLOADS = {
+    "demo1080": dict(scene="SCENE_DEMO", width=1920, height=1080, iterations=64, depth=8,
+                     label="demo scene (9 spheres + area light) 1920x1080, 64 spp, depth 8"),
+    "synth10k": dict(scene="SCENE_SYNTH10K", width=1920, height=1080, iterations=16, depth=8,
+                     label="synthetic 10 007-sphere scene 1920x1080, 16 spp, depth 8"),
+    "mixed16": dict(scene="SCENE_MIXED", width=1920, height=1080, iterations=32, depth=16,
+                    label="mixed diffuse/specular/glass grid 1920x1080, 32 spp, depth 16"),
+}
+PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (256 CU x 256 flop/clk x 2.4 GHz)
+
+
+def flops_per_ray(n_spheres: int) -> int:
+    """Algorithmic flops of one Intersect call + one bounce of shading: 17 per sphere test
+    (3 sub, two 5-flop dots, b*b, -, r*r, +) + 21 for hit point/normal + 100 for the BSDF."""
+    return 17 * n_spheres + 121
+
+
+def cpu_baseline(pt, wl, mats, sph, lights, cam):
+    """Time the CPU oracle on a bounded sample of the same workload (about 10-30 s of CPU work)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    w, h = wl["width"], wl["height"]
+    # ~15 s of CPU work: the oracle does about 5.4e6 Intersect calls/s/thread on 9 spheres
+    # and scales with the number of sphere tests per call
+    rate = 5.4e6 * 24.0 / (len(sph) + 15.0)
+    budget_rays = 15.0 * threads * rate
+    rays_per_row = w * 4 * 3.7
+    if budget_rays >= rays_per_row * h:
+        iters, rows = max(1, min(wl["iterations"], int(budget_rays / (rays_per_row * h)))), h
+    else:
+        iters, rows = 1, min(h, max(threads, int(budget_rays / rays_per_row)))
+    y0 = (h - rows) // 2
+    t0 = time.perf_counter()
+    _, _, _, rays = O.oracle_render(cam.pod, mats, sph, lights, 1, wl["depth"], first_iteration=1,
+                                    n_iterations=iters, rect=(0, y0, w, y0 + rows), n_threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt, "unit": "path-bounces/s", "cores": threads, "kind": "port",
+            "sample": f"{wl['label']}: rows {y0}..{y0 + rows} x {iters} iteration(s), {rays} Intersect calls "
+                      f"in {dt:.2f} s on {threads} threads (oracle/pt_oracle.c)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="demo1080", choices=sorted(WORKLOADS))
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 regeneration, 1 classic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    pt = importlib.import_module("cuda-pathtracer_amd")
+    sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
+    wl = WORKLOADS[args.workload]
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(getattr(pt, wl["scene"]), 1)
+    cam = pt.Camera(eye, look, up, wl["width"], wl["height"], 0.0, 0.0, fov)
+    tr = pt.Pathtracer(cam, wl["depth"], seed=1)
+    tr.Init(mats, sph, lights)
+    tr.SetKernelVariant(args.variant)
+    tr.SetStream(torch.cuda.current_stream().cuda_stream)
+    if world > 1:
+        tr.SetAccumMode(pt.ACCUM_SUM)
+    buf = torch.zeros(wl["width"] * wl["height"] * 3, dtype=torch.float32, device=device)
+    first, n_it = sharding.sample_range(rank, world, wl["iterations"])
+
+    def step():
+        tr.Reset()
+        tr.SetIteration(first - 1)
+        tr.RunN(buf, n_it, sync=False)
+        if world > 1:
+            sharding.reduce_to_root(buf, dist, 0)
+            if rank == 0:
+                buf.mul_(1.0 / float(world * n_it))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    tr.ResetCounters()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    rays_local = tr.RayCount()
+
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    r = torch.tensor([rays_local], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    dt_max, rays_total = float(t.item()), float(r.item())
+
+    # Per-launch kernel time with HIP events on the kernel's own stream (outside the timed
+    # region so that reading them does not perturb it): a few extra launches of the same step.
+    ev_ms = []
+    for _ in range(max(3, min(args.steps, 5))):
+        tr.Reset(); tr.SetIteration(first - 1)
+        tr.RunN(buf, n_it, sync=True)
+        ev_ms.append(tr.LastKernelMs())
+    ev_ms.sort()
+    launch_ms = sum(ev_ms) / len(ev_ms)
+    rays_per_launch = rays_local / max(1, args.steps)
+    fpr = flops_per_ray(len(sph))
+    achieved = rays_per_launch * fpr / (launch_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        out = {
+            "metric": "path-bounces/sec",
+            "value": rays_total / dt_max,
+            "unit": "path-bounces/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl["label"], "paths_per_step_per_gpu": wl["width"] * wl["height"] * 4 * n_it,
+                       "bounces_per_step_per_gpu": rays_per_launch, "spheres": int(len(sph)),
+                       "parallelism": "single" if world == 1 else f"sample-range split x{world} + RCCL reduce(sum)",
+                       "kernel_variant": args.variant},
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "kernel": "render_kernel", "launch_ms": launch_ms,
+                         "flops_per_bounce": fpr, "bounces_per_launch": rays_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pt, wl, mats, sph, lights, cam)
+        print(json.dumps(out), flush=True)
+
+    tr.Release()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,262 @@
+"""Python host-side mirror of the reference's ``Pathtracer`` interface over libptmi's C ABI.
+
+The reference's host code is C++ (``pathtracer.h:38-65``, ``main.cpp:128-190``); the C++ mirror
+lives in ``host/pathtracer.hpp``.  This module is the same thin layer for Python callers
+(tests, ``bench.py``): ctypes bindings of ``include/ptmi.h`` plus a ``Pathtracer`` class with the
+reference's method names.  PyTorch is only plumbing here: callers allocate the frame buffer
+as a CUDA tensor and pass ``tensor.data_ptr()``.
+
+There is no fallback: if ``libptmi.so`` has not been built, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptmi.so")
+
+# ---- POD layouts of include/ptmi.h -------------------------------------------------------------
+CAMERA_DTYPE = np.dtype([("pos", "<f4", 3), ("px_x", "<f4", 3), ("px_y", "<f4", 3),
+                         ("first_ray_dir", "<f4", 3), ("width", "<u4"), ("height", "<u4")])
+MATERIAL_DTYPE = np.dtype([("color", "<f4", 3), ("coef", "<f4"), ("type", "<i4")])
+SPHERE_DTYPE = np.dtype([("pos", "<f4", 3), ("radius", "<f4"), ("material_id", "<u4"),
+                         ("light_id", "<i4")])
+# light.h:47-52: the union {Point pos; uint32 primId} is exposed as raw words
+LIGHT_DTYPE = np.dtype([("type", "<i4"), ("u_bits", "<u4", 3), ("intensity", "<f4", 3)])
+assert CAMERA_DTYPE.itemsize == 56 and MATERIAL_DTYPE.itemsize == 20
+assert SPHERE_DTYPE.itemsize == 24 and LIGHT_DTYPE.itemsize == 28
+
+DIFFUSE, SPECULAR, TRANSMISSIVE = 0, 1, 2
+POINT_LIGHT, AREA_LIGHT = 0, 1
+ACCUM_RUNNING_MEAN, ACCUM_SUM = 0, 1
+HIT_MISS, HIT_NOT_TRACED = -1, -2
+SCENE_DEMO, SCENE_SYNTH10K, SCENE_MIXED = 0, 1, 2
+PT_OK, PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_DEVICE, PT_ERR_NOMEM = 0, -1, -2, -3, -4
+
+# Every symbol include/ptmi.h declares: (name, restype, argtypes)
+_vp, _u32, _u64, _i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+_pu32, _pu64, _pf = ctypes.POINTER(_u32), ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_float)
+ABI = [
+    ("pt_create", _i32, [ctypes.POINTER(_vp), _vp, _i32, _u64]),
+    ("pt_init_scene", _i32, [_vp, _vp, _u32, _vp, _u32, _vp, _u32]),
+    ("pt_destroy", _i32, [_vp]),
+    ("pt_last_error", ctypes.c_char_p, [_vp]),
+    ("pt_run", _i32, [_vp, _vp, _i32]),
+    ("pt_run_n", _i32, [_vp, _vp, _u32, _i32]),
+    ("pt_reset", _i32, [_vp]),
+    ("pt_iteration", _u32, [_vp]),
+    ("pt_set_camera", _i32, [_vp, _vp]),
+    ("pt_set_stream", _i32, [_vp, _vp]),
+    ("pt_set_accum_mode", _i32, [_vp, _i32]),
+    ("pt_set_iteration", _i32, [_vp, _u32]),
+    ("pt_set_row_bands", _i32, [_vp, _u32, _u32, _u32]),
+    ("pt_ray_count", _i32, [_vp, _pu64]),
+    ("pt_reset_counters", _i32, [_vp]),
+    ("pt_set_kernel_variant", _i32, [_vp, _i32]),
+    ("pt_last_kernel_ms", _i32, [_vp, _pf]),
+    ("pt_read_image", _i32, [_vp, _vp, _vp]),
+    ("pt_debug_trace", _i32, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _pu64]),
+    ("pt_camera_init", _i32, [_vp, _vp, _vp, _vp, _u32, _u32, ctypes.c_float]),
+    ("pt_scene_build", _i32, [_i32, _u64, _vp, _pu32, _vp, _pu32, _vp, _pu32, _vp, _vp, _vp, _pf]),
+    ("pt_version", _i32, []),
+]
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load libptmi.so (built in-tree by ``make lib``); raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not built: run `make lib` (hipcc --offload-arch=gfx950); "
+                              "there is no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, restype, argtypes in ABI:
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+class PtError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libptmi error {code}: {message}")
+        self.code = code
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f3(v) -> np.ndarray:
+    a = np.ascontiguousarray(v, dtype=np.float32)
+    if a.shape != (3,):
+        raise ValueError("expected 3 floats")
+    return a
+
+
+class Camera:
+    """``Camera(eye, lookAt, up, width, height, lensRadius, focalDistance, fov)``, camera.h:31-57.
+
+    Lens radius and focal distance are accepted and ignored, as in the reference ("TODO depth of
+    field", camera.h:68)."""
+
+    def __init__(self, eye, look_at, up, width: int, height: int, lens_radius: float = 0.0,
+                 focal_distance: float = 0.0, fov: float = 60.0):
+        self.eye, self.look_at, self.up = _f3(eye), _f3(look_at), _f3(up)
+        self.fov = float(fov)
+        self.pod = np.zeros(1, dtype=CAMERA_DTYPE)
+        rc = load_library().pt_camera_init(_ptr(self.pod), _ptr(self.eye), _ptr(self.look_at),
+                                           _ptr(self.up), width, height, self.fov)
+        if rc != PT_OK:
+            raise PtError(rc, "pt_camera_init: invalid arguments")
+
+    def Width(self) -> int:
+        return int(self.pod["width"][0])
+
+    def Height(self) -> int:
+        return int(self.pod["height"][0])
+
+
+def build_scene(scene_id: int = SCENE_DEMO, seed: int = 1):
+    """Built-in scenes.  Returns (materials, spheres, lights, (eye, look_at, up, fov))."""
+    lib = load_library()
+    nm, ns, nl = _u32(0), _u32(0), _u32(0)
+    eye, look_at, up = (np.zeros(3, np.float32) for _ in range(3))
+    fov = ctypes.c_float(0)
+    rc = lib.pt_scene_build(scene_id, seed, None, ctypes.byref(nm), None, ctypes.byref(ns), None,
+                            ctypes.byref(nl), _ptr(eye), _ptr(look_at), _ptr(up), ctypes.byref(fov))
+    if rc != PT_OK:
+        raise PtError(rc, f"pt_scene_build: unknown scene {scene_id}")
+    mats = np.zeros(nm.value, MATERIAL_DTYPE)
+    sph = np.zeros(ns.value, SPHERE_DTYPE)
+    lights = np.zeros(nl.value, LIGHT_DTYPE)
+    rc = lib.pt_scene_build(scene_id, seed, _ptr(mats), ctypes.byref(nm), _ptr(sph), ctypes.byref(ns),
+                            _ptr(lights), ctypes.byref(nl), None, None, None, None)
+    if rc != PT_OK:
+        raise PtError(rc, "pt_scene_build failed")
+    return mats, sph, lights, (eye, look_at, up, float(fov.value))
+
+
+class Pathtracer:
+    """Mirror of the reference's ``class Pathtracer`` (pathtracer.h:38-65).
+
+    ``Pathtracer(camera, nBounces)``, ``Init(mv, pv, lv)``, ``Run(devBuffer)``, ``Reset()``,
+    ``GetIteration()``, ``Release()`` keep the reference's meaning; ``seed`` replaces the
+    reference's ``time(NULL)`` cuRAND seed (pathtracer.cu:216)."""
+
+    def __init__(self, camera, n_bounces: int, seed: int = 1):
+        self._lib = load_library()
+        pod = camera.pod if isinstance(camera, Camera) else np.ascontiguousarray(camera, CAMERA_DTYPE)
+        self.width, self.height = int(pod["width"].reshape(-1)[0]), int(pod["height"].reshape(-1)[0])
+        self.max_bounces = int(n_bounces)
+        h = _vp()
+        rc = self._lib.pt_create(ctypes.byref(h), _ptr(pod), n_bounces, seed)
+        if rc != PT_OK:
+            raise PtError(rc, self._lib.pt_last_error(None).decode())
+        self._h = h
+
+    def _check(self, rc: int):
+        if rc != PT_OK:
+            raise PtError(rc, self._lib.pt_last_error(self._h).decode())
+
+    # -- the reference's five methods -----------------------------------------------------------
+    def Init(self, materials, primitives, lights) -> bool:
+        m = np.ascontiguousarray(materials, MATERIAL_DTYPE)
+        p = np.ascontiguousarray(primitives, SPHERE_DTYPE)
+        l = np.ascontiguousarray(lights, LIGHT_DTYPE)
+        self._check(self._lib.pt_init_scene(self._h, _ptr(m), len(m), _ptr(p), len(p), _ptr(l), len(l)))
+        return True
+
+    def Run(self, dev_buffer) -> None:
+        """``dev_buffer``: device pointer (int) or a torch CUDA tensor of width*height*3 floats."""
+        self._check(self._lib.pt_run(self._h, _vp(_devptr(dev_buffer, self)), 1))
+
+    def Reset(self) -> None:
+        self._check(self._lib.pt_reset(self._h))
+
+    def GetIteration(self) -> int:
+        return int(self._lib.pt_iteration(self._h))
+
+    def Release(self) -> None:
+        if self._h:
+            self._lib.pt_destroy(self._h)
+            self._h = None
+
+    # -- extensions ---------------------------------------------------------------------------
+    def RunHost(self, host_buffer: np.ndarray) -> None:
+        assert host_buffer.dtype == np.float32 and host_buffer.size == self.width * self.height * 3
+        self._check(self._lib.pt_run(self._h, _ptr(host_buffer), 0))
+
+    def RunN(self, dev_buffer, n_iterations: int, sync: bool = True) -> None:
+        self._check(self._lib.pt_run_n(self._h, _vp(_devptr(dev_buffer, self)), n_iterations, int(sync)))
+
+    def SetCamera(self, camera) -> None:
+        pod = camera.pod if isinstance(camera, Camera) else np.ascontiguousarray(camera, CAMERA_DTYPE)
+        self._check(self._lib.pt_set_camera(self._h, _ptr(pod)))
+
+    def SetStream(self, stream_ptr: int) -> None:
+        self._check(self._lib.pt_set_stream(self._h, _vp(stream_ptr)))
+
+    def SetAccumMode(self, mode: int) -> None:
+        self._check(self._lib.pt_set_accum_mode(self._h, mode))
+
+    def SetIteration(self, iteration: int) -> None:
+        self._check(self._lib.pt_set_iteration(self._h, iteration))
+
+    def SetRowBands(self, band_rows: int, rank: int, world: int) -> None:
+        self._check(self._lib.pt_set_row_bands(self._h, band_rows, rank, world))
+
+    def SetKernelVariant(self, variant: int) -> None:
+        self._check(self._lib.pt_set_kernel_variant(self._h, variant))
+
+    def RayCount(self) -> int:
+        v = _u64(0)
+        self._check(self._lib.pt_ray_count(self._h, ctypes.byref(v)))
+        return int(v.value)
+
+    def ResetCounters(self) -> None:
+        self._check(self._lib.pt_reset_counters(self._h))
+
+    def LastKernelMs(self) -> float:
+        v = ctypes.c_float(0)
+        self._check(self._lib.pt_last_kernel_ms(self._h, ctypes.byref(v)))
+        return float(v.value)
+
+    def ReadImage(self, dev_buffer) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), np.float32)
+        self._check(self._lib.pt_read_image(self._h, _vp(_devptr(dev_buffer, self)), _ptr(out)))
+        return out
+
+    def DebugTrace(self, x0: int, y0: int, x1: int, y1: int, iteration: int):
+        """Returns (hit_ids[h,w,4,mb+1], radiance[h,w,4,3], pixel_rgb[h,w,3], ray_count)."""
+        w, h = x1 - x0, y1 - y0
+        hits = np.empty((h, w, 4, self.max_bounces + 1), np.int32)
+        rad = np.empty((h, w, 4, 3), np.float32)
+        rgb = np.empty((h, w, 3), np.float32)
+        cnt = _u64(0)
+        self._check(self._lib.pt_debug_trace(self._h, x0, y0, x1, y1, iteration, _ptr(hits), _ptr(rad),
+                                             _ptr(rgb), ctypes.byref(cnt)))
+        return hits, rad, rgb, int(cnt.value)
+
+    def __del__(self):
+        try:
+            self.Release()
+        except Exception:
+            pass
+
+
+def _devptr(buf, pt: "Pathtracer") -> int:
+    if isinstance(buf, int):
+        return buf
+    # torch tensor (kept duck-typed so that importing this module does not import torch)
+    if not buf.is_cuda or not buf.is_contiguous() or buf.numel() != pt.width * pt.height * 3:
+        raise ValueError("frame buffer must be a contiguous CUDA float32 tensor of width*height*3")
+    if str(buf.dtype) != "torch.float32":
+        raise ValueError("frame buffer must be float32")
+    return buf.data_ptr()

@@ -1,0 +1,459 @@
+// C ABI of libptmi (include/ptmi.h): host-side driver of the render kernels.
+//
+// Mirrors the life cycle of the reference's Pathtracer (pathtracer.h:38-65,
+// pathtracer.cu:172-258): create -> Init (scene upload) -> Run per iteration -> Reset /
+// Release.  There is deliberately no CPU rendering path: every rendering entry point needs a
+// gfx950 device and reports PT_ERR_DEVICE otherwise.
+#include "ptmi.h"
+#include "pt_kernels.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace ptmi;
+
+struct pt_context {
+    pt_camera_pod camera;
+    int max_bounces;
+    uint64_t seed;
+    uint32_t iteration;   // Pathtracer::iteration, pathtracer.h:58
+    bool fresh;           // nothing accumulated since create/reset
+    int accum_mode;
+    uint32_t band_rows, band_rank, band_world;
+    int regen_min_idle;
+    hipStream_t stream;
+    int device;
+    // scene (device)
+    float4 *d_sph, *d_aux, *d_mat, *d_light;
+    int *d_mat_type;
+    uint32_t n_prims, n_mats, n_lights;
+    bool scene_ready;
+    // misc device state
+    unsigned long long *d_ray_counter;
+    float *d_internal_buffer; // frame buffer owned by the library when the caller passes host memory
+    hipEvent_t ev_start, ev_stop;
+    bool timed;
+    std::string error;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(pt_context *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->error = buf; else g_create_error = buf;
+    return code;
+}
+
+#define PT_HIP(h, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((h), PT_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_));    \
+    } while (0)
+
+static bool camera_ok(const pt_camera_pod *c)
+{
+    return c && c->width > 0 && c->height > 0 && (uint64_t)c->width * c->height <= 0x7fffffffull / 3;
+}
+
+extern "C" {
+
+int pt_version(void) { return 100; }
+
+const char *pt_last_error(pt_handle h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint64_t seed)
+{
+    if (!out) return fail(nullptr, PT_ERR_INVALID, "pt_create: out is NULL");
+    *out = nullptr;
+    if (!camera_ok(camera)) return fail(nullptr, PT_ERR_INVALID, "pt_create: bad camera (width/height)");
+    if (max_bounces < 0 || max_bounces > 1024)
+        return fail(nullptr, PT_ERR_INVALID, "pt_create: max_bounces %d out of range [0,1024]", max_bounces);
+
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0)
+        return fail(nullptr, PT_ERR_DEVICE, "pt_create: no HIP device (%s); libptmi has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    int dev = 0;
+    PT_HIP(nullptr, hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    PT_HIP(nullptr, hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PT_ERR_DEVICE, "pt_create: device %d is %s; libptmi is built for gfx950 only",
+                    dev, prop.gcnArchName);
+
+    pt_context *h = new (std::nothrow) pt_context();
+    if (!h) return fail(nullptr, PT_ERR_NOMEM, "pt_create: out of host memory");
+    h->camera = *camera;
+    h->max_bounces = max_bounces;
+    h->seed = seed;
+    h->iteration = 0;
+    h->fresh = true;
+    h->accum_mode = PT_ACCUM_RUNNING_MEAN;
+    h->band_rows = 0; h->band_rank = 0; h->band_world = 1;
+    h->regen_min_idle = 1;
+    h->stream = nullptr;
+    h->device = dev;
+    h->d_sph = h->d_aux = h->d_mat = h->d_light = nullptr;
+    h->d_mat_type = nullptr;
+    h->n_prims = h->n_mats = h->n_lights = 0;
+    h->scene_ready = false;
+    h->d_ray_counter = nullptr;
+    h->d_internal_buffer = nullptr;
+    h->ev_start = h->ev_stop = nullptr;
+    h->timed = false;
+
+    if (hipMalloc((void **)&h->d_ray_counter, sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(h->d_ray_counter, 0, sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess) {
+        pt_destroy(h);
+        return fail(nullptr, PT_ERR_DEVICE, "pt_create: device allocation failed");
+    }
+    *out = h;
+    return PT_OK;
+}
+
+static void free_scene(pt_context *h)
+{
+    if (h->d_sph) (void)hipFree(h->d_sph);
+    if (h->d_aux) (void)hipFree(h->d_aux);
+    if (h->d_mat) (void)hipFree(h->d_mat);
+    if (h->d_light) (void)hipFree(h->d_light);
+    if (h->d_mat_type) (void)hipFree(h->d_mat_type);
+    h->d_sph = h->d_aux = h->d_mat = h->d_light = nullptr;
+    h->d_mat_type = nullptr;
+    h->scene_ready = false;
+}
+
+int pt_destroy(pt_handle h)
+{
+    if (!h) return PT_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    free_scene(h);
+    if (h->d_ray_counter) (void)hipFree(h->d_ray_counter);
+    if (h->d_internal_buffer) (void)hipFree(h->d_internal_buffer);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    delete h;
+    return PT_OK;
+}
+
+int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_materials,
+                  const pt_sphere *spheres, uint32_t n_spheres,
+                  const pt_light *lights, uint32_t n_lights)
+{
+    if (!h) return PT_ERR_INVALID;
+    if ((n_materials && !materials) || (n_spheres && !spheres) || (n_lights && !lights))
+        return fail(h, PT_ERR_INVALID, "pt_init_scene: NULL array with non-zero count");
+    if (n_spheres > 0x7fffffffu / 2) return fail(h, PT_ERR_INVALID, "pt_init_scene: too many spheres");
+    for (uint32_t i = 0; i < n_spheres; ++i) {
+        if (spheres[i].material_id >= n_materials)
+            return fail(h, PT_ERR_INVALID, "pt_init_scene: sphere %u references material %u of %u", i,
+                        spheres[i].material_id, n_materials);
+        if (spheres[i].light_id >= (int32_t)n_lights)
+            return fail(h, PT_ERR_INVALID, "pt_init_scene: sphere %u references light %d of %u", i,
+                        spheres[i].light_id, n_lights);
+    }
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    free_scene(h);
+
+    // Repack the reference's AoS Primitive (primitive.h:77-81) to SoA float4 pairs.  r*r and
+    // 1/r are the same single IEEE operations the reference performs per test / per hit
+    // (primitive.h:42,74), so hoisting them to the host does not change a bit.
+    std::vector<float4> sph(n_spheres ? n_spheres : 1), aux(n_spheres ? n_spheres : 1);
+    for (uint32_t i = 0; i < n_spheres; ++i) {
+        const pt_sphere &s = spheres[i];
+        sph[i] = make_float4(s.pos[0], s.pos[1], s.pos[2], s.radius * s.radius);
+        float mbits, lbits;
+        memcpy(&mbits, &s.material_id, 4);
+        memcpy(&lbits, &s.light_id, 4);
+        aux[i] = make_float4(1.f / s.radius, mbits, lbits, s.radius);
+    }
+    std::vector<float4> mat(n_materials ? n_materials : 1), light(n_lights ? n_lights : 1);
+    std::vector<int> mtype(n_materials ? n_materials : 1);
+    for (uint32_t i = 0; i < n_materials; ++i) {
+        mat[i] = make_float4(materials[i].color[0], materials[i].color[1], materials[i].color[2],
+                             materials[i].coef);
+        mtype[i] = materials[i].type;
+    }
+    for (uint32_t i = 0; i < n_lights; ++i)
+        light[i] = make_float4(lights[i].intensity[0], lights[i].intensity[1], lights[i].intensity[2], 0.f);
+
+    PT_HIP(h, hipMalloc((void **)&h->d_sph, sph.size() * sizeof(float4)));
+    PT_HIP(h, hipMalloc((void **)&h->d_aux, aux.size() * sizeof(float4)));
+    PT_HIP(h, hipMalloc((void **)&h->d_mat, mat.size() * sizeof(float4)));
+    PT_HIP(h, hipMalloc((void **)&h->d_light, light.size() * sizeof(float4)));
+    PT_HIP(h, hipMalloc((void **)&h->d_mat_type, mtype.size() * sizeof(int)));
+    PT_HIP(h, hipMemcpy(h->d_sph, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(h, hipMemcpy(h->d_aux, aux.data(), aux.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(h, hipMemcpy(h->d_mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(h, hipMemcpy(h->d_light, light.data(), light.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(h, hipMemcpy(h->d_mat_type, mtype.data(), mtype.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->n_prims = n_spheres; h->n_mats = n_materials; h->n_lights = n_lights;
+    h->scene_ready = true;
+    return PT_OK;
+}
+
+int pt_set_camera(pt_handle h, const pt_camera_pod *camera)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (!camera_ok(camera)) return fail(h, PT_ERR_INVALID, "pt_set_camera: bad camera");
+    if (camera->width != h->camera.width || camera->height != h->camera.height)
+        return fail(h, PT_ERR_INVALID, "pt_set_camera: image size is latched at pt_create (%ux%u)",
+                    h->camera.width, h->camera.height);
+    h->camera = *camera;
+    return PT_OK;
+}
+
+int pt_set_stream(pt_handle h, void *hip_stream)
+{
+    if (!h) return PT_ERR_INVALID;
+    h->stream = (hipStream_t)hip_stream;
+    return PT_OK;
+}
+
+int pt_set_accum_mode(pt_handle h, int mode)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (mode != PT_ACCUM_RUNNING_MEAN && mode != PT_ACCUM_SUM)
+        return fail(h, PT_ERR_INVALID, "pt_set_accum_mode: unknown mode %d", mode);
+    h->accum_mode = mode;
+    return PT_OK;
+}
+
+int pt_set_iteration(pt_handle h, uint32_t iteration)
+{
+    if (!h) return PT_ERR_INVALID;
+    h->iteration = iteration;
+    return PT_OK;
+}
+
+int pt_set_row_bands(pt_handle h, uint32_t band_rows, uint32_t rank, uint32_t world)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (world == 0 || rank >= world) return fail(h, PT_ERR_INVALID, "pt_set_row_bands: rank %u of %u", rank, world);
+    if (world > 1 && (band_rows == 0 || band_rows % 16 != 0))
+        return fail(h, PT_ERR_INVALID, "pt_set_row_bands: band_rows %u must be a positive multiple of 16", band_rows);
+    h->band_rows = world > 1 ? band_rows : 0;
+    h->band_rank = rank;
+    h->band_world = world;
+    return PT_OK;
+}
+
+int pt_set_kernel_variant(pt_handle h, int variant)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (variant == 0) h->regen_min_idle = 1;
+    else if (variant == 1) h->regen_min_idle = 64;
+    else if (variant >= 2 && variant <= 64) h->regen_min_idle = variant; // experimental: idle-lane threshold
+    else return fail(h, PT_ERR_INVALID, "pt_set_kernel_variant: unknown variant %d", variant);
+    return PT_OK;
+}
+
+int pt_reset(pt_handle h)
+{
+    if (!h) return PT_ERR_INVALID;
+    h->iteration = 0;
+    h->fresh = true;
+    return PT_OK;
+}
+
+uint32_t pt_iteration(pt_handle h) { return h ? h->iteration : 0; }
+
+static void fill_params(const pt_context *h, RenderParams &p)
+{
+    memset(&p, 0, sizeof p);
+    for (int i = 0; i < 3; ++i) {
+        p.cam_pos[i] = h->camera.pos[i];
+        p.cam_pxx[i] = h->camera.px_x[i];
+        p.cam_pxy[i] = h->camera.px_y[i];
+        p.cam_first[i] = h->camera.first_ray_dir[i];
+    }
+    p.width = h->camera.width; p.height = h->camera.height;
+    p.sph = h->d_sph; p.aux = h->d_aux; p.mat = h->d_mat; p.mat_type = h->d_mat_type; p.light = h->d_light;
+    p.n_prims = h->n_prims; p.n_mats = h->n_mats; p.n_lights = h->n_lights;
+    p.seed = h->seed;
+    p.max_bounces = h->max_bounces;
+    p.regen_min_idle = h->regen_min_idle;
+}
+
+static uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// Enqueue n iterations on the handle's stream.
+static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
+{
+    if (!h->scene_ready) return fail(h, PT_ERR_STATE, "render before pt_init_scene");
+    if (!dbuf) return fail(h, PT_ERR_INVALID, "render: buffer is NULL");
+    if (n_iterations == 0) return PT_OK;
+    if (h->iteration > 0xffffffffu - n_iterations) return fail(h, PT_ERR_INVALID, "iteration counter overflow");
+
+    RenderParams p;
+    fill_params(h, p);
+    p.x0 = 0; p.y0 = 0; p.x1 = p.width; p.y1 = p.height;
+    p.first_iteration = h->iteration + 1;
+    p.n_iterations = n_iterations;
+    p.accum_mode = h->accum_mode;
+    p.overwrite = h->accum_mode == PT_ACCUM_RUNNING_MEAN ? (p.first_iteration == 1) : (h->fresh ? 1 : 0);
+    p.buffer = dbuf;
+    p.ray_counter = h->d_ray_counter;
+
+    uint32_t grid_y;
+    if (h->band_world > 1) {
+        const uint32_t n_bands = div_up(p.height, h->band_rows);
+        const uint32_t owned = n_bands > h->band_rank ? div_up(n_bands - h->band_rank, h->band_world) : 0;
+        p.band_rows = h->band_rows; p.band_rank = h->band_rank; p.band_world = h->band_world;
+        grid_y = owned * (h->band_rows / 16);
+    } else {
+        p.band_rows = div_up(p.height, 16) * 16; p.band_rank = 0; p.band_world = 1;
+        grid_y = p.band_rows / 16;
+    }
+    const bool tiled = p.n_prims > kMaxResidentSpheres;
+    if (grid_y > 0) {
+        PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
+        PT_HIP(h, launch_render(p, div_up(p.width, 16), grid_y, tiled, false, h->stream));
+        PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
+        h->timed = true;
+    }
+    h->iteration += n_iterations;
+    h->fresh = false;
+    return PT_OK;
+}
+
+int pt_run_n(pt_handle h, float *device_buffer, uint32_t n_iterations, int sync)
+{
+    if (!h) return PT_ERR_INVALID;
+    int rc = enqueue(h, device_buffer, n_iterations);
+    if (rc != PT_OK) return rc;
+    if (sync) PT_HIP(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
+int pt_run(pt_handle h, float *buffer, int buffer_is_device)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (!buffer) return fail(h, PT_ERR_INVALID, "pt_run: buffer is NULL");
+    if (buffer_is_device) return pt_run_n(h, buffer, 1, 1);
+
+    const size_t bytes = (size_t)h->camera.width * h->camera.height * 3 * sizeof(float);
+    if (!h->d_internal_buffer) {
+        PT_HIP(h, hipMalloc((void **)&h->d_internal_buffer, bytes));
+        PT_HIP(h, hipMemsetAsync(h->d_internal_buffer, 0, bytes, h->stream));
+    }
+    int rc = enqueue(h, h->d_internal_buffer, 1);
+    if (rc != PT_OK) return rc;
+    PT_HIP(h, hipMemcpyAsync(buffer, h->d_internal_buffer, bytes, hipMemcpyDeviceToHost, h->stream));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
+int pt_read_image(pt_handle h, const float *device_buffer, float *host_rgb)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (!device_buffer || !host_rgb) return fail(h, PT_ERR_INVALID, "pt_read_image: NULL pointer");
+    const size_t bytes = (size_t)h->camera.width * h->camera.height * 3 * sizeof(float);
+    PT_HIP(h, hipMemcpyAsync(host_rgb, device_buffer, bytes, hipMemcpyDeviceToHost, h->stream));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
+int pt_ray_count(pt_handle h, uint64_t *out)
+{
+    if (!h || !out) return PT_ERR_INVALID;
+    unsigned long long v = 0;
+    PT_HIP(h, hipMemcpyAsync(&v, h->d_ray_counter, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    *out = (uint64_t)v;
+    return PT_OK;
+}
+
+int pt_reset_counters(pt_handle h)
+{
+    if (!h) return PT_ERR_INVALID;
+    PT_HIP(h, hipMemsetAsync(h->d_ray_counter, 0, sizeof(unsigned long long), h->stream));
+    return PT_OK;
+}
+
+int pt_last_kernel_ms(pt_handle h, float *ms)
+{
+    if (!h || !ms) return PT_ERR_INVALID;
+    if (!h->timed) return fail(h, PT_ERR_STATE, "pt_last_kernel_ms: nothing was launched yet");
+    PT_HIP(h, hipEventSynchronize(h->ev_stop));
+    PT_HIP(h, hipEventElapsedTime(ms, h->ev_start, h->ev_stop));
+    return PT_OK;
+}
+
+int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                   uint32_t iteration, int32_t *hit_ids, float *radiance, float *pixel_rgb,
+                   uint64_t *ray_count)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (!h->scene_ready) return fail(h, PT_ERR_STATE, "pt_debug_trace before pt_init_scene");
+    if (x0 >= x1 || y0 >= y1 || x1 > h->camera.width || y1 > h->camera.height)
+        return fail(h, PT_ERR_INVALID, "pt_debug_trace: bad rectangle [%u,%u)x[%u,%u)", x0, x1, y0, y1);
+    if (iteration == 0) return fail(h, PT_ERR_INVALID, "pt_debug_trace: iterations are 1-based");
+
+    const size_t n_pix = (size_t)(x1 - x0) * (y1 - y0);
+    const size_t n_paths = n_pix * 4;
+    const size_t hit_elems = n_paths * (size_t)(h->max_bounces + 1);
+    int32_t *d_hits = nullptr;
+    float *d_rad = nullptr, *d_rgb = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    int rc = PT_OK;
+    hipError_t e = hipSuccess;
+    std::vector<int32_t> init;
+
+    #define DBG_HIP(call) do { e = (call); if (e != hipSuccess) { rc = fail(h, PT_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e)); goto cleanup; } } while (0)
+    if (hit_ids) {
+        init.assign(hit_elems, PT_HIT_NOT_TRACED);
+        DBG_HIP(hipMalloc((void **)&d_hits, hit_elems * sizeof(int32_t)));
+        DBG_HIP(hipMemcpyAsync(d_hits, init.data(), hit_elems * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    }
+    if (radiance) DBG_HIP(hipMalloc((void **)&d_rad, n_paths * 3 * sizeof(float)));
+    if (pixel_rgb) DBG_HIP(hipMalloc((void **)&d_rgb, n_pix * 3 * sizeof(float)));
+    DBG_HIP(hipMalloc((void **)&d_cnt, sizeof(unsigned long long)));
+    DBG_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
+    {
+        RenderParams p;
+        fill_params(h, p);
+        p.x0 = x0; p.y0 = y0; p.x1 = x1; p.y1 = y1;
+        p.band_rows = div_up(y1 - y0, 16) * 16; p.band_rank = 0; p.band_world = 1;
+        p.first_iteration = iteration;
+        p.n_iterations = 1;
+        p.accum_mode = PT_ACCUM_SUM;
+        p.overwrite = 1;
+        p.buffer = nullptr;
+        p.ray_counter = d_cnt;
+        p.hit_ids = d_hits; p.path_rad = d_rad; p.pixel_rgb = d_rgb;
+        const bool tiled = p.n_prims > kMaxResidentSpheres;
+        DBG_HIP(launch_render(p, div_up(x1 - x0, 16), p.band_rows / 16, tiled, true, h->stream));
+    }
+    if (hit_ids) DBG_HIP(hipMemcpyAsync(hit_ids, d_hits, hit_elems * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (radiance) DBG_HIP(hipMemcpyAsync(radiance, d_rad, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (pixel_rgb) DBG_HIP(hipMemcpyAsync(pixel_rgb, d_rgb, n_pix * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    {
+        unsigned long long cnt = 0;
+        DBG_HIP(hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+        DBG_HIP(hipStreamSynchronize(h->stream));
+        if (ray_count) *ray_count = (uint64_t)cnt;
+    }
+    #undef DBG_HIP
+cleanup:
+    if (rc != PT_OK) (void)hipStreamSynchronize(h->stream);
+    if (d_hits) (void)hipFree(d_hits);
+    if (d_rad) (void)hipFree(d_rad);
+    if (d_rgb) (void)hipFree(d_rgb);
+    if (d_cnt) (void)hipFree(d_cnt);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,193 @@
+/*
+ * libptmi -- C ABI of the MI355X (gfx950) path-tracing hot path.
+ *
+ * Drop-in boundary: the five methods of the reference's `class Pathtracer`
+ * (pathtracer.h:38-65; implementation pathtracer.cu:172-258) and the scene/camera PODs they
+ * consume.  Plain pointers and sizes only; every function returns 0 on success or a negative
+ * pt_status, never exits the process (the reference's CudaSafeCall, cutil.h:27-52, calls
+ * exit(-1)), and pt_last_error() returns the reason as text.
+ *
+ * Rendering runs on the current HIP device, on the stream given by pt_set_stream() (default:
+ * the null stream).  There is no CPU fallback: without a usable gfx950 device every rendering
+ * call fails with PT_ERR_DEVICE.
+ *
+ * Random numbers: the reference's per-frame cuRAND buffer (pathtracer.cu:207,224) is replaced
+ * by Philox4x32-10 keyed by `seed` and addressed by (pixel index, iteration, slot, stream);
+ * stream 0 slots 0..1 are a pixel's 8 camera jitters (pathtracer.cu:70), stream 1 slot b holds
+ * bounce b's {u, v, roulette} (pathtracer.cu:131,141,155).  uint32 -> float is
+ * (x >> 8) * 2^-24.
+ */
+#ifndef PTMI_H
+#define PTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_context *pt_handle;
+
+typedef enum {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1, /* bad argument */
+    PT_ERR_STATE = -2,   /* call order (e.g. pt_run before pt_init_scene) */
+    PT_ERR_DEVICE = -3,  /* HIP error, or no gfx950 device */
+    PT_ERR_NOMEM = -4
+} pt_status;
+
+/* What Camera::GenerateRay reads (camera.h:66-72): the members Camera::UpdateParameter
+ * derives (camera.h:144-158) plus the image size (camera.h:165-166). */
+typedef struct {
+    float pos[3];
+    float px_x[3];
+    float px_y[3];
+    float first_ray_dir[3];
+    uint32_t width, height;
+} pt_camera_pod;
+
+/* material.h:25 */
+enum { PT_DIFFUSE = 0, PT_SPECULAR = 1, PT_TRANSMISSIVE = 2 };
+/* material.h:45-47 */
+typedef struct {
+    float color[3];
+    float coef;
+    int32_t type;
+} pt_material;
+
+/* primitive.h:78-81 (the bounding box, primitive.h:77, is never read by the trace loop) */
+typedef struct {
+    float pos[3];
+    float radius;
+    uint32_t material_id;
+    int32_t light_id; /* -1: not a light (primitive.h:31,75) */
+} pt_sphere;
+
+/* light.h:34 */
+enum { PT_POINT_LIGHT = 0, PT_AREA_LIGHT = 1 };
+/* light.h:47-52 */
+typedef struct {
+    int32_t type;
+    union {
+        float pos[3];
+        uint32_t prim_id;
+    } u;
+    float intensity[3];
+} pt_light;
+
+/* Frame-buffer update rule of one iteration (1-based number `it`, pixel colour `c`):
+ *   PT_ACCUM_RUNNING_MEAN  buffer = (buffer*(it-1) + c) * (1/it)     RenderKernel,
+ *                          pathtracer.cu:104-109 (iteration 1 overwrites the buffer)
+ *   PT_ACCUM_SUM           buffer += c; the first iteration after pt_reset() overwrites.
+ *                          For sharding a render by sample range over several GPUs. */
+enum { PT_ACCUM_RUNNING_MEAN = 0, PT_ACCUM_SUM = 1 };
+
+/* hit_ids sentinels of pt_debug_trace */
+enum { PT_HIT_MISS = -1, PT_HIT_NOT_TRACED = -2 };
+
+/* ---- life cycle ------------------------------------------------------------------------ */
+
+/* Pathtracer::Pathtracer(Camera*, int nBounces), pathtracer.h:40-43.  The camera is copied;
+ * width/height are latched here as in the reference. */
+int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint64_t seed);
+
+/* Pathtracer::Init, pathtracer.cu:172-220: uploads the scene (repacked to SoA).  The arrays
+ * may be freed after the call.  n_materials is honoured (the reference copies pv.size()
+ * materials, pathtracer.cu:194). */
+int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_materials,
+                  const pt_sphere *spheres, uint32_t n_spheres,
+                  const pt_light *lights, uint32_t n_lights);
+
+/* Pathtracer::Release, pathtracer.cu:249-258, plus destruction of the handle. */
+int pt_destroy(pt_handle h);
+
+/* Text of the last error of this handle (h may be NULL: last error of pt_create). */
+const char *pt_last_error(pt_handle h);
+
+/* ---- rendering ------------------------------------------------------------------------- */
+
+/* Pathtracer::Run, pathtracer.cu:222-243: renders iteration ++iteration (4 jittered paths per
+ * pixel) and updates `buffer` (width*height*3 floats, interleaved RGB, row 0 on top).
+ * buffer_is_device != 0: a device pointer, updated in place like the reference's mapped PBO.
+ * buffer_is_device == 0: a host pointer; the library keeps the device copy and writes the
+ * current image to it.  Blocking: returns after the kernel has completed. */
+int pt_run(pt_handle h, float *buffer, int buffer_is_device);
+
+/* n_iterations consecutive Run() calls in ONE launch on a device buffer: each pixel keeps its
+ * accumulator in registers, results are identical to n calls of pt_run.  sync == 0 returns
+ * after enqueueing on the stream. */
+int pt_run_n(pt_handle h, float *device_buffer, uint32_t n_iterations, int sync);
+
+/* Pathtracer::Reset, pathtracer.cu:245-247: iteration = 0. */
+int pt_reset(pt_handle h);
+
+/* Pathtracer::GetIteration, pathtracer.h:49. */
+uint32_t pt_iteration(pt_handle h);
+
+/* The reference dereferences its Camera* on every Run (pathtracer.cu:232); a C caller
+ * passes the new value explicitly.  Width and height must not change. */
+int pt_set_camera(pt_handle h, const pt_camera_pod *camera);
+
+/* ---- sharding / plumbing (no counterpart in the single-GPU reference) -------------------- */
+
+int pt_set_stream(pt_handle h, void *hip_stream);
+int pt_set_accum_mode(pt_handle h, int mode);
+/* Next pt_run renders iteration `iteration`+1: a rank that owns samples [a+1, a+n] calls
+ * pt_reset(); pt_set_iteration(a). */
+int pt_set_iteration(pt_handle h, uint32_t iteration);
+/* Tile split: the image is cut into horizontal bands of band_rows rows (a multiple of 16);
+ * this instance renders bands b with b % world == rank and leaves other pixels untouched.
+ * world == 1 (default) renders everything. */
+int pt_set_row_bands(pt_handle h, uint32_t band_rows, uint32_t rank, uint32_t world);
+/* Total number of Intersect calls ("rays", one per path bounce) since creation or the last
+ * pt_reset_counters; waits for the stream. */
+int pt_ray_count(pt_handle h, uint64_t *out);
+int pt_reset_counters(pt_handle h);
+/* Kernel variant: 0 = persistent lanes with path regeneration (default), 1 = one lane per
+ * pixel-iteration without regeneration.  Results are identical; for profiling. */
+int pt_set_kernel_variant(pt_handle h, int variant);
+/* HIP-event time of the last pt_run/pt_run_n launch in milliseconds (waits for it). */
+int pt_last_kernel_ms(pt_handle h, float *ms);
+
+/* Copies a device frame buffer to the host (pt_read_image(h, dev, host)); with PT_ACCUM_SUM
+ * the caller divides by the number of iterations. */
+int pt_read_image(pt_handle h, const float *device_buffer, float *host_rgb);
+
+/* Parity hook: traces iteration `iteration` of the pixel rectangle [x0,x1) x [y0,y1) with the
+ * production device functions and returns, per path ([pixel row-major][sub-sample 0..3]):
+ *   hit_ids  [..][max_bounces+1] int32  primitive index of the k-th Intersect call
+ *            (scene.h:71-94), PT_HIT_MISS, or PT_HIT_NOT_TRACED
+ *   radiance [..][3] float              the Color Trace() returned (pathtracer.cu:169)
+ *   pixel_rgb[pixel][3] float           (L0+L1+L2+L3)*(1/4), pathtracer.cu:94-101
+ * Host pointers, any may be NULL.  Does not touch the frame buffer or the iteration. */
+int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                   uint32_t iteration, int32_t *hit_ids, float *radiance, float *pixel_rgb,
+                   uint64_t *ray_count);
+
+/* ---- host-side scene helpers (plain host code, no device needed) ------------------------- */
+
+/* Camera::Camera + UpdateParameter, camera.h:31-57,144-158. */
+int pt_camera_init(pt_camera_pod *out, const float eye[3], const float look_at[3],
+                   const float up[3], uint32_t width, uint32_t height, float fov_deg);
+
+typedef enum {
+    PT_SCENE_DEMO = 0,      /* InitScene "scene 2", main.cpp:129-164: 9 spheres, 1 area light */
+    PT_SCENE_SYNTH10K = 1,  /* demo room + 10 000 procedural spheres */
+    PT_SCENE_MIXED = 2      /* demo room + 8x8 grid cycling diffuse/specular/glass */
+} pt_scene_id;
+
+/* Two-call pattern: with NULL arrays only the counts are written.  eye/look_at/up/fov_deg
+ * (may be NULL) receive the camera of main.cpp:129. */
+int pt_scene_build(int scene_id, uint64_t seed,
+                   pt_material *materials, uint32_t *n_materials,
+                   pt_sphere *spheres, uint32_t *n_spheres,
+                   pt_light *lights, uint32_t *n_lights,
+                   float eye[3], float look_at[3], float up[3], float *fov_deg);
+
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+int pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI_H */

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- regenerates tests/golden/*.npz.
+
+Runs ONLY in the development container: it drives oracle/_ref/libpt_ref.so, the host build of
+the reference's own headers + Trace() (see oracle/ref_harness.cpp), and stores inputs and
+outputs as data.  The GPU box has no reference tree; the tests there read these files.
+
+    make -C oracle ref && python oracle/gen_golden.py
+
+Every case stores: the camera arguments and the camera POD the reference's constructor
+derived, the scene arrays, seed / depth / iteration range, and the reference's outputs:
+image, per-path hit-id sequences (int16), per-path radiance and the Intersect-call count.
+"""
+from __future__ import annotations
+
+import hashlib
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import oracle_py as O  # noqa: E402
+
+pt = importlib.import_module("cuda-pathtracer_amd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def case(name, scene_id, width, height, max_bounces, seed, first_iteration=1, n_iterations=1,
+         scene_seed=1, scene=None, store_paths=True, libm_stats=False):
+    if scene is None:
+        mats, sph, lights, (eye, look, up, fov) = pt.build_scene(scene_id, scene_seed)
+    else:
+        mats, sph, lights, (eye, look, up, fov) = scene
+    cam = O.camera_init(eye, look, up, width, height, fov, lib=O.load_ref(), fn="ref_camera_init")
+    img, hits, rad, rays = O.ref_render(eye, look, up, width, height, fov, mats, sph, lights, seed,
+                                        max_bounces, first_iteration, n_iterations, want_paths=True)
+    assert hits.min() >= -2 and hits.max() < 32767
+    out = dict(eye=eye, look_at=look, up=up, fov=np.float32(fov), width=width, height=height,
+               camera_pod=cam, materials=mats, spheres=sph, lights=lights, seed=np.uint64(seed),
+               max_bounces=max_bounces, first_iteration=first_iteration, n_iterations=n_iterations,
+               image=img, ray_count=np.uint64(rays),
+               hit_ids_sha256=sha(hits), path_radiance_sha256=sha(rad))
+    if store_paths:
+        out["hit_ids"] = hits.astype(np.int16)
+        out["path_radiance"] = rad
+    if libm_stats:
+        # the same reference build with libm's sinf/cosf instead of the deterministic pair:
+        # bounds what the substitution does to the image (documentation, not a parity target)
+        img2, hits2, _, rays2 = O.ref_render(eye, look, up, width, height, fov, mats, sph, lights,
+                                             seed, max_bounces, first_iteration, n_iterations,
+                                             want_paths=True, libm=True)
+        out["libm_image_rmse"] = np.float64(np.sqrt(((img2.astype(np.float64) - img) ** 2).mean()))
+        out["libm_mean_abs_diff_of_means"] = np.float64(abs(img2.mean(dtype=np.float64) - img.mean(dtype=np.float64)))
+        out["libm_hit_mismatch_fraction"] = np.float64((hits2 != hits).mean())
+        out["libm_first_hit_mismatch"] = np.int64((hits2[..., 0] != hits[..., 0]).sum())
+        out["libm_ray_count"] = np.uint64(rays2)
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {width}x{height} d{max_bounces} it{first_iteration}+{n_iterations} rays={rays} "
+          f"mean={img.mean():.6f} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def empty_scene():
+    mats = np.zeros(1, O.MATERIAL_DTYPE)
+    mats["color"] = 0.5
+    return (mats, np.zeros(0, O.SPHERE_DTYPE), np.zeros(0, O.LIGHT_DTYPE),
+            (np.array([0, 45, 79.5], np.float32), np.array([0, 35, 0], np.float32),
+             np.array([0, 1, 0], np.float32), 60.0))
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    ref = O.load_ref()
+    assert ref.ref_uses_libm_sincos() == 0
+
+    # BASELINE config 1: demo scene 256x256, 1 iteration, depth 4
+    case("demo_256x256_d4_it1", pt.SCENE_DEMO, 256, 256, 4, seed=1, store_paths=False, libm_stats=True)
+    # the same at a size whose per-path data is small enough to commit
+    case("demo_64x64_d4_it1", pt.SCENE_DEMO, 64, 64, 4, seed=1)
+    # running mean over iterations 1..4, and a resumed range 3..4 on a ragged size
+    case("demo_64x48_d8_it1-4", pt.SCENE_DEMO, 64, 48, 8, seed=7, n_iterations=4)
+    case("demo_37x21_d8_it3-4", pt.SCENE_DEMO, 37, 21, 8, seed=7, first_iteration=3, n_iterations=2)
+    # depth 0 (only emission of the first hit is ever seen) and depth 16 (Russian roulette)
+    case("demo_32x32_d0_it1", pt.SCENE_DEMO, 32, 32, 0, seed=3)
+    case("mixed_64x64_d16_it1-2", pt.SCENE_MIXED, 64, 64, 16, seed=11, n_iterations=2)
+    # 10 007 spheres: exercises the LDS-tiled scan (index order / tie-break across tiles)
+    case("synth10k_32x32_d8_it1", pt.SCENE_SYNTH10K, 32, 32, 8, seed=5)
+    # no primitives at all: every primary ray misses
+    case("empty_16x16_d4_it1", None, 16, 16, 4, seed=1, scene=empty_scene())
+
+    # camera PODs derived by the reference's constructor at the sizes of the BASELINE configs
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
+    sizes = [(256, 256), (640, 480), (1920, 1080), (3840, 2160), (17, 5)]
+    pods = np.concatenate([O.camera_init(eye, look, up, w, h, fov, lib=ref, fn="ref_camera_init")
+                           for (w, h) in sizes])
+    # an off-axis camera as well
+    eye2, look2, up2 = np.array([10, 20, 60], np.float32), np.array([-5, 30, -40], np.float32), \
+        np.array([0.1, 1, 0], np.float32)
+    pod2 = O.camera_init(eye2, look2, up2, 320, 200, 75.0, lib=ref, fn="ref_camera_init")
+    np.savez_compressed(os.path.join(GOLDEN, "cameras.npz"), eye=eye, look_at=look, up=up,
+                        fov=np.float32(fov), sizes=np.array(sizes, np.uint32), pods=pods,
+                        eye2=eye2, look_at2=look2, up2=up2, fov2=np.float32(75.0), pod2=pod2,
+                        sizeof=np.array([ref.ref_sizeof(i) for i in range(11)], np.int32))
+    print("cameras.npz written")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU oracle for the path-tracing hot path.  It is the checker,
+ * never the thing shipped or measured: the product library (libptmi.so) does not include,
+ * link or call anything in this directory.
+ *
+ * Plain-C restatement of the reference's per-pixel pipeline
+ *   GenerateRayPool (pathtracer.cu:62-75) -> RenderKernel (pathtracer.cu:80-110)
+ *   -> Trace (pathtracer.cu:112-170) -> Intersect / SampleMaterial (scene.h:71-94,177-221)
+ * with every fp32 expression evaluated in the reference's order (no fused multiply-add).
+ * Pinned against the reference's own headers compiled for host (oracle/_ref, built by
+ * oracle/Makefile) through the golden vectors in tests/golden/.
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The four derived camera vectors GenerateRay reads (camera.h:66-72,165-171). */
+typedef struct {
+    float pos[3];
+    float px_x[3];
+    float px_y[3];
+    float first_ray_dir[3];
+    uint32_t width, height;
+} ptor_camera;
+
+/* material.h:45-47 */
+typedef struct {
+    float color[3];
+    float coef;
+    int32_t type; /* 0 DIFFUSE, 1 SPECULAR, 2 TRANSMISSIVE (material.h:25) */
+} ptor_material;
+
+/* primitive.h:78-81 without the never-read bounding box */
+typedef struct {
+    float pos[3];
+    float radius;
+    uint32_t material_id;
+    int32_t light_id; /* -1: not a light */
+} ptor_sphere;
+
+/* light.h:47-52 */
+typedef struct {
+    int32_t type; /* 0 POINT_LIGHT, 1 AREA_LIGHT (light.h:34) */
+    union {
+        float pos[3];
+        uint32_t prim_id;
+    } u;
+    float intensity[3];
+} ptor_light;
+
+enum { PTOR_ACCUM_RUNNING_MEAN = 0, PTOR_ACCUM_SUM = 1 };
+
+/* hit_ids sentinel values */
+enum { PTOR_HIT_MISS = -1, PTOR_HIT_NOT_TRACED = -2 };
+
+/* Camera ctor + UpdateParameter, camera.h:31-57,144-158. */
+void ptor_camera_init(ptor_camera *out, const float eye[3], const float look_at[3],
+                      const float up[3], uint32_t width, uint32_t height, float fov_deg);
+
+/* Philox4x32-10 block and the float map, exported for the known-answer tests. */
+void ptor_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void ptor_uniforms(uint64_t seed, uint32_t pixel, uint32_t iteration, uint32_t slot,
+                   uint32_t stream, float out[4]);
+void ptor_sincos(float x, float *s, float *c);
+
+/*
+ * Render iterations first_iteration .. first_iteration+n_iterations-1 (1-based, the value
+ * RenderKernel receives as `iteration`, pathtracer.cu:239) of the pixel rectangle
+ * [x0,x1) x [y0,y1) into `buffer` (width*height*3 interleaved RGB, row 0 on top).
+ *
+ * accum_mode RUNNING_MEAN: buffer = (buffer*(it-1) + c) * (1/it)   (pathtracer.cu:104-109)
+ *            SUM:          buffer += c
+ *
+ * Optional outputs (may be NULL), indexed [iteration][pixel of the rectangle, row-major]
+ * [sub-sample 0..3]:
+ *   hit_ids       [...][max_bounces+1] int32: primitive index returned by the k-th Intersect
+ *                 call of the path, PTOR_HIT_MISS, or PTOR_HIT_NOT_TRACED
+ *   path_radiance [...][3] float: the Color Trace returned
+ * ray_count (may be NULL) receives the number of Intersect calls.
+ * n_threads > 1 splits the rows over that many pthreads (results are identical).
+ * Returns 0, or -1 on invalid arguments.
+ */
+int ptor_render(const ptor_camera *cam,
+                const ptor_material *mats, uint32_t n_mats,
+                const ptor_sphere *prims, uint32_t n_prims,
+                const ptor_light *lights, uint32_t n_lights,
+                uint64_t seed, int max_bounces,
+                uint32_t first_iteration, uint32_t n_iterations,
+                uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                int accum_mode, float *buffer,
+                int32_t *hit_ids, float *path_radiance, uint64_t *ray_count,
+                int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_ORACLE_H */

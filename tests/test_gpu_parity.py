@@ -1,0 +1,270 @@
+"""T2 of the parity ladder: the HIP kernels (through the C ABI) against the CPU oracle and the
+golden vectors of the reference's host build.
+
+Bar: hit-index sequences, per-path radiance, pixel colours and the running mean are BIT-EXACT
+(integer work and, because both sides evaluate the same IEEE fp32 expression trees without
+fused multiply-add, the floating-point results too).  The only tolerance in this file is for
+PT_ACCUM_SUM vs the running mean, which sum in a different order: rtol 2e-6 * sqrt(n) + atol 1e-6.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def make_tracer(pt, g, variant=0):
+    tr = pt.Pathtracer(g["camera_pod"], int(g["max_bounces"]), int(g["seed"]))
+    tr.Init(g["materials"], g["spheres"], g["lights"])
+    tr.SetKernelVariant(variant)
+    return tr
+
+
+def render(torch, tr, first_iteration, n_iterations, batched=True, buf=None):
+    if buf is None:
+        buf = torch.zeros(tr.height * tr.width * 3, dtype=torch.float32, device="cuda")
+    tr.Reset()
+    tr.SetIteration(first_iteration - 1)
+    if batched:
+        tr.RunN(buf, n_iterations)
+    else:
+        for _ in range(n_iterations):
+            tr.Run(buf)
+    torch.cuda.synchronize()
+    return buf
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_image_matches_golden_bit_exact(pt, torch_cuda, name):
+    """Frame buffer after the fixture's iteration range == the reference host build's."""
+    g = load_golden(name)
+    tr = make_tracer(pt, g)
+    tr.ResetCounters()
+    buf = render(torch_cuda, tr, int(g["first_iteration"]), int(g["n_iterations"]))
+    img = buf.cpu().numpy().reshape(g["image"].shape)
+    assert tr.RayCount() == int(g["ray_count"])
+    assert img.tobytes() == g["image"].tobytes()
+    assert tr.GetIteration() == int(g["first_iteration"]) + int(g["n_iterations"]) - 1
+    tr.Release()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_hit_ids_and_path_radiance_match_golden(pt, torch_cuda, name):
+    g = load_golden(name)
+    tr = make_tracer(pt, g)
+    w, h = int(g["width"]), int(g["height"])
+    hits_all, rad_all, rays = [], [], 0
+    for it in range(int(g["first_iteration"]), int(g["first_iteration"]) + int(g["n_iterations"])):
+        hits, rad, rgb, cnt = tr.DebugTrace(0, 0, w, h, it)
+        hits_all.append(hits); rad_all.append(rad); rays += cnt
+        # pixel colour is the in-order sum of the four paths times 1/4 (pathtracer.cu:94-101)
+        expect = (((rad[:, :, 0] + rad[:, :, 1]) + rad[:, :, 2]) + rad[:, :, 3]) * np.float32(0.25)
+        assert rgb.tobytes() == expect.astype(np.float32).tobytes()
+    hits_all, rad_all = np.stack(hits_all), np.stack(rad_all)
+    assert rays == int(g["ray_count"])
+    assert sha(hits_all) == str(g["hit_ids_sha256"])
+    assert sha(rad_all) == str(g["path_radiance_sha256"])
+    if "hit_ids" in g.files:
+        assert np.array_equal(hits_all, g["hit_ids"].astype(np.int32))
+    tr.Release()
+
+
+def test_matches_oracle_on_seeded_random_scenes(pt, O, torch_cuda):
+    """Same seeded inputs through the HIP path and the oracle, sizes the oracle does in seconds."""
+    from test_oracle_golden import _random_scene
+    rng = np.random.default_rng(2024)
+    eye, look, up = [0, 45, 79.5], [0, 35, 0], [0, 1, 0]
+    for n, (w, h), mb, seed in [(1, (16, 16), 3, 1), (5, (40, 24), 6, 3), (33, (31, 17), 12, 2**40 + 5),
+                                (70, (24, 24), 20, 9), (600, (32, 16), 8, 77), (1500, (20, 20), 6, 5)]:
+        mats, sph, lights = _random_scene(rng, O, n) if n > 1 else _random_scene(rng, O, 2)
+        if n == 1:
+            sph = sph[:1].copy(); sph["light_id"] = 0; lights = lights[:1].copy()
+        cam = pt.Camera(eye, look, up, w, h, 0, 0, 50.0)
+        ref_img, ref_hits, ref_rad, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, seed, mb,
+                                                               first_iteration=2, n_iterations=2,
+                                                               want_paths=True)
+        tr = pt.Pathtracer(cam, mb, seed)
+        tr.Init(mats, sph, lights)
+        tr.ResetCounters()
+        buf = render(torch_cuda, tr, 2, 2)
+        assert buf.cpu().numpy().tobytes() == ref_img.tobytes(), (n, w, h)
+        assert tr.RayCount() == ref_rays
+        for k, it in enumerate((2, 3)):
+            hits, rad, _, _ = tr.DebugTrace(0, 0, w, h, it)
+            assert np.array_equal(hits, ref_hits[k]), (n, it)
+            assert rad.tobytes() == ref_rad[k].tobytes(), (n, it)
+        tr.Release()
+
+
+def test_debug_trace_sub_rectangle(pt, torch_cuda):
+    g = load_golden("demo_64x64_d4_it1")
+    tr = make_tracer(pt, g)
+    hits, rad, _, _ = tr.DebugTrace(5, 9, 41, 30, 1)
+    assert np.array_equal(hits, g["hit_ids"][0, 9:30, 5:41].astype(np.int32))
+    assert rad.tobytes() == np.ascontiguousarray(g["path_radiance"][0, 9:30, 5:41]).tobytes()
+    tr.Release()
+
+
+def test_run_per_iteration_equals_batched_and_host_buffer(pt, torch_cuda):
+    """n x pt_run == pt_run_n(n) == pt_run on a host buffer (Pathtracer::Run semantics)."""
+    g = load_golden("demo_64x48_d8_it1-4")
+    tr = make_tracer(pt, g)
+    a = render(torch_cuda, tr, 1, 4, batched=True).cpu().numpy()
+    b = render(torch_cuda, tr, 1, 4, batched=False).cpu().numpy()
+    assert a.tobytes() == b.tobytes() == g["image"].tobytes()
+    host = np.zeros(64 * 48 * 3, np.float32)
+    tr.Reset()
+    for k in range(4):
+        tr.RunHost(host)
+        assert tr.GetIteration() == k + 1
+    assert host.tobytes() == g["image"].tobytes()
+    # Reset(): the next Run overwrites (iteration 1 weights the old content with 0)
+    tr.Reset()
+    assert tr.GetIteration() == 0
+    buf = torch_cuda.full((64 * 48 * 3,), 123.0, device="cuda")
+    tr.Run(buf)
+    one = render(torch_cuda, tr, 1, 1).cpu().numpy()
+    assert buf.cpu().numpy().tobytes() == one.tobytes()
+    tr.Release()
+
+
+def test_kernel_variants_agree(pt, torch_cuda):
+    """Path regeneration changes scheduling only: identical bits with and without it."""
+    g = load_golden("mixed_64x64_d16_it1-2")
+    imgs = []
+    for variant in (0, 1, 16):
+        tr = make_tracer(pt, g, variant)
+        imgs.append(render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes())
+        tr.Release()
+    assert imgs[0] == imgs[1] == imgs[2] == g["image"].tobytes()
+
+
+def test_tile_split_is_bit_exact(pt, torch_cuda):
+    """Row bands rendered by different instances into zero-filled buffers sum to the 1-instance image."""
+    g = load_golden("demo_64x48_d8_it1-4")
+    total = torch_cuda.zeros(64 * 48 * 3, device="cuda")
+    for rank in range(3):
+        tr = make_tracer(pt, g)
+        tr.SetRowBands(16, rank, 3)
+        buf = render(torch_cuda, tr, 1, 4)
+        img = buf.cpu().numpy().reshape(48, 64, 3)
+        for band in range(3):
+            rows = img[band * 16:(band + 1) * 16]
+            if band % 3 != rank:
+                assert not rows.any()
+        total += buf
+        tr.Release()
+    assert total.cpu().numpy().tobytes() == g["image"].tobytes()
+
+
+def test_sample_range_split_sums_to_the_mean(pt, torch_cuda):
+    g = load_golden("demo_64x48_d8_it1-4")
+    total = torch_cuda.zeros(64 * 48 * 3, device="cuda")
+    rays = 0
+    for rank in range(2):
+        tr = make_tracer(pt, g)
+        tr.SetAccumMode(pt.ACCUM_SUM)
+        tr.ResetCounters()
+        buf = torch_cuda.full((64 * 48 * 3,), 7.0, device="cuda")   # stale content must be overwritten
+        render(torch_cuda, tr, 1 + 2 * rank, 2, buf=buf)
+        rays += tr.RayCount()
+        total += buf
+        tr.Release()
+    assert rays == int(g["ray_count"])
+    n = 4
+    np.testing.assert_allclose(total.cpu().numpy() / n, g["image"].ravel(), rtol=2e-6 * np.sqrt(n), atol=1e-6)
+
+
+def test_camera_update_takes_effect_next_run(pt, torch_cuda):
+    g = load_golden("demo_64x64_d4_it1")
+    tr = make_tracer(pt, g)
+    a = render(torch_cuda, tr, 1, 1).cpu().numpy()
+    cam2 = pt.Camera([5, 40, 70], g["look_at"], g["up"], 64, 64, 0, 0, float(g["fov"]))
+    tr.SetCamera(cam2)
+    b = render(torch_cuda, tr, 1, 1).cpu().numpy()
+    assert a.tobytes() != b.tobytes()
+    tr.SetCamera(g["camera_pod"])
+    c = render(torch_cuda, tr, 1, 1).cpu().numpy()
+    assert a.tobytes() == c.tobytes() == g["image"].tobytes()
+    with pytest.raises(pt.PtError):
+        tr.SetCamera(pt.Camera(g["eye"], g["look_at"], g["up"], 32, 64))
+    tr.Release()
+
+
+def test_errors(pt, torch_cuda):
+    g = load_golden("demo_32x32_d0_it1")
+    tr = pt.Pathtracer(g["camera_pod"], 4, 1)
+    buf = torch_cuda.zeros(32 * 32 * 3, device="cuda")
+    with pytest.raises(pt.PtError) as e:
+        tr.Run(buf)                      # Run before Init
+    assert e.value.code == pt.PT_ERR_STATE
+    bad = g["spheres"].copy()
+    bad["material_id"][3] = 6
+    with pytest.raises(pt.PtError) as e:
+        tr.Init(g["materials"], bad, g["lights"])
+    assert e.value.code == pt.PT_ERR_INVALID and "material" in str(e.value)
+    bad = g["spheres"].copy()
+    bad["light_id"][3] = 1
+    with pytest.raises(pt.PtError):
+        tr.Init(g["materials"], bad, g["lights"])
+    with pytest.raises(pt.PtError):
+        tr.SetRowBands(10, 0, 2)         # not a multiple of 16
+    with pytest.raises(pt.PtError):
+        tr.SetRowBands(16, 2, 2)
+    with pytest.raises(pt.PtError):
+        tr.SetAccumMode(5)
+    tr.Init(g["materials"], g["spheres"], g["lights"])
+    with pytest.raises(pt.PtError):
+        tr.DebugTrace(0, 0, 33, 32, 1)
+    with pytest.raises(pt.PtError):
+        tr.DebugTrace(0, 0, 32, 32, 0)
+    with pytest.raises(ValueError):
+        tr.Run(torch_cuda.zeros(10, device="cuda"))
+    tr.Release()
+    with pytest.raises(pt.PtError):
+        pt.Pathtracer(g["camera_pod"], -1, 1)
+
+
+def test_full_size_properties_1080p(pt, O, torch_cuda):
+    """BASELINE's 1080p demo config through size-independent properties: determinism, iteration
+    composition (2+2 == 4, bit-exact), ray count == per-path Intersect calls, and a sampled
+    band of rows against the oracle."""
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
+    cam = pt.Camera(eye, look, up, 1920, 1080, 0, 0, fov)
+    tr = pt.Pathtracer(cam, 8, 1)
+    tr.Init(mats, sph, lights)
+    tr.ResetCounters()
+    a = render(torch_cuda, tr, 1, 4)
+    rays4 = tr.RayCount()
+    b = render(torch_cuda, tr, 1, 4)
+    assert torch_cuda.equal(a, b)
+    assert tr.RayCount() == 2 * rays4
+    c = torch_cuda.zeros_like(a)
+    tr.Reset(); tr.RunN(c, 2); tr.RunN(c, 2)
+    assert torch_cuda.equal(a, c)
+    assert 3.0 < rays4 / (1920 * 1080 * 4 * 4) < 4.5     # ~3.7 Intersect calls per path
+    assert bool(torch_cuda.isfinite(a).all())
+    # rows 536..543 against the oracle (all 1080 rows are rendered, not only 1072)
+    img = a.cpu().numpy().reshape(1080, 1920, 3)
+    ref, _, _, _ = O.oracle_render(cam.pod, mats, sph, lights, 1, 8, n_iterations=4,
+                                   rect=(0, 536, 1920, 544), n_threads=8)
+    assert img[536:544].tobytes() == ref[536:544].tobytes()
+    ref, _, _, _ = O.oracle_render(cam.pod, mats, sph, lights, 1, 8, n_iterations=4,
+                                   rect=(0, 1072, 1920, 1080), n_threads=8)
+    assert img[1072:].tobytes() == ref[1072:].tobytes()
+    tr.Release()
