@@ -131,11 +131,16 @@ def main():
         step()
     fence()
     tr.ResetCounters()
+    # HIP events on the stream the kernels run on (the library was handed torch's current stream)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         step()
+    ev1.record()
     fence()
     dt = time.perf_counter() - t0
+    region_ms = ev0.elapsed_time(ev1)
     rays_local = tr.RayCount()
 
     t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -145,15 +150,10 @@ def main():
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
     dt_max, rays_total = float(t.item()), float(r.item())
 
-    # Per-launch kernel time with HIP events on the kernel's own stream (outside the timed
-    # region so that reading them does not perturb it): a few extra launches of the same step.
-    ev_ms = []
-    for _ in range(max(3, min(args.steps, 5))):
-        tr.Reset(); tr.SetIteration(first - 1)
-        tr.RunN(buf, n_it, sync=True)
-        ev_ms.append(tr.LastKernelMs())
-    ev_ms.sort()
-    launch_ms = sum(ev_ms) / len(ev_ms)
+    # Average launch duration of the render kernel: at N=1 the timed region is nothing but the
+    # K launches, so the event pair around it gives it directly; with a reduce in the step the
+    # library's own event pair around the last launch is used instead.
+    launch_ms = region_ms / args.steps if world == 1 else tr.LastKernelMs()
     rays_per_launch = rays_local / max(1, args.steps)
     fpr = flops_per_ray(len(sph))
     achieved = rays_per_launch * fpr / (launch_ms * 1e-3) / 1e12
