@@ -59,6 +59,8 @@ ABI = [
     ("pt_last_kernel_ms", _i32, [_vp, _pf]),
     ("pt_read_image", _i32, [_vp, _vp, _vp]),
     ("pt_debug_trace", _i32, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _pu64]),
+    ("pt_selftest_eval", _i32, [_vp, _i32, _vp, _vp, _vp, _u64]),
+    ("pt_selftest_exhaustive", _i32, [_vp, _i32, _pu64]),
     ("pt_camera_init", _i32, [_vp, _vp, _vp, _vp, _u32, _u32, ctypes.c_float]),
     ("pt_scene_build", _i32, [_i32, _u64, _vp, _pu32, _vp, _pu32, _vp, _pu32, _vp, _vp, _vp, _pf]),
     ("pt_version", _i32, []),
@@ -243,6 +245,19 @@ class Pathtracer:
         self._check(self._lib.pt_debug_trace(self._h, x0, y0, x1, y1, iteration, _ptr(hits), _ptr(rad),
                                              _ptr(rgb), ctypes.byref(cnt)))
         return hits, rad, rgb, int(cnt.value)
+
+    def SelftestEval(self, op: int, a: np.ndarray, b: np.ndarray | None = None) -> np.ndarray:
+        a = np.ascontiguousarray(a, np.float32)
+        bb = None if b is None else np.ascontiguousarray(b, np.float32)
+        out = np.empty_like(a)
+        self._check(self._lib.pt_selftest_eval(self._h, op, _ptr(a), None if bb is None else _ptr(bb),
+                                               _ptr(out), a.size))
+        return out
+
+    def SelftestExhaustive(self, op: int) -> int:
+        v = _u64(0)
+        self._check(self._lib.pt_selftest_exhaustive(self._h, op, ctypes.byref(v)))
+        return int(v.value)
 
     def __del__(self):
         try:

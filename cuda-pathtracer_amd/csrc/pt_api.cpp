@@ -456,4 +456,51 @@ cleanup:
     return rc;
 }
 
+int pt_selftest_eval(pt_handle h, int op, const float *a, const float *b, float *out, uint64_t n)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (op < 0 || op > 4 || !a || !out || (op == 2 && !b)) return fail(h, PT_ERR_INVALID, "pt_selftest_eval: bad arguments");
+    if (n == 0) return PT_OK;
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    int rc = PT_OK;
+    hipError_t e = hipSuccess;
+    #define ST_HIP(call) do { e = (call); if (e != hipSuccess) { rc = fail(h, PT_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e)); goto done; } } while (0)
+    ST_HIP(hipMalloc((void **)&da, n * sizeof(float)));
+    ST_HIP(hipMalloc((void **)&dout, n * sizeof(float)));
+    ST_HIP(hipMemcpyAsync(da, a, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (b) {
+        ST_HIP(hipMalloc((void **)&db, n * sizeof(float)));
+        ST_HIP(hipMemcpyAsync(db, b, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    ST_HIP(launch_selftest_eval(op, da, db, dout, n, h->stream));
+    ST_HIP(hipMemcpyAsync(out, dout, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    ST_HIP(hipStreamSynchronize(h->stream));
+done:
+    if (rc != PT_OK) (void)hipStreamSynchronize(h->stream);
+    if (da) (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
+int pt_selftest_exhaustive(pt_handle h, int op, uint64_t *mismatches)
+{
+    if (!h || !mismatches) return PT_ERR_INVALID;
+    if (op < 0 || op > 2) return fail(h, PT_ERR_INVALID, "pt_selftest_exhaustive: op must be 0, 1 or 2");
+    unsigned long long *d = nullptr, v = 0;
+    int rc = PT_OK;
+    hipError_t e = hipSuccess;
+    ST_HIP(hipMalloc((void **)&d, sizeof v));
+    ST_HIP(hipMemsetAsync(d, 0, sizeof v, h->stream));
+    ST_HIP(launch_selftest_exhaustive(op, d, h->stream));
+    ST_HIP(hipMemcpyAsync(&v, d, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    ST_HIP(hipStreamSynchronize(h->stream));
+    *mismatches = (uint64_t)v;
+    #undef ST_HIP
+done:
+    if (rc != PT_OK) (void)hipStreamSynchronize(h->stream);
+    if (d) (void)hipFree(d);
+    return rc;
+}
+
 } // extern "C"

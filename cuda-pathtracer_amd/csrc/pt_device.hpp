@@ -19,6 +19,62 @@ namespace ptmi {
 
 #define PT_DEV __device__ __forceinline__
 
+// ---- correctly rounded sqrt, 1/x and a/b ------------------------------------------------------
+// hipcc's IEEE expansions of sqrtf and '/' carry denormal pre-scaling, class checks and
+// div_scale/div_fixup steps made of half-rate compare/select instructions (~55 and ~40 issue
+// cycles).  For operands in a comfortable exponent range the Newton/Markstein sequences below
+// give the same correctly rounded result in ~22 / ~17 / ~24 cycles of full-rate FMAs; outside
+// the range (zero, denormal, huge, inf, NaN, negative sqrt argument) the generic expansion
+// runs.  Correct rounding makes them bit-identical to the host's sqrtf and '/'; pt_selftest
+// checks every float (sqrt, 1/x) and 2^32 random pairs (a/b) against the generic expansion.
+PT_DEV bool in_exp_range(float x, uint32_t lo_biased, uint32_t hi_biased)
+{
+    // true iff lo <= biased exponent of |x| < hi (sign ignored)
+    return ((__float_as_uint(x) & 0x7fffffffu) - (lo_biased << 23)) < ((hi_biased - lo_biased) << 23);
+}
+
+PT_DEV float pt_sqrt(float x)
+{
+    // positive, 2^-100 <= x < 2^100 (a set sign bit makes the unsigned difference huge)
+    if (__builtin_expect((__float_as_uint(x) - (27u << 23)) < (200u << 23), 1)) {
+        const float r = __builtin_amdgcn_rsqf(x);
+        float g = x * r, h = 0.5f * r;
+        const float e = __builtin_fmaf(-h, g, 0.5f);
+        g = __builtin_fmaf(g, e, g);
+        h = __builtin_fmaf(h, e, h);
+        const float d = __builtin_fmaf(-g, g, x);
+        return __builtin_fmaf(d, h, g);
+    }
+    return __builtin_sqrtf(x);
+}
+
+PT_DEV float rcp_newton(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.f);
+    r = __builtin_fmaf(e, r, r);
+    e = __builtin_fmaf(-x, r, 1.f);
+    return __builtin_fmaf(e, r, r);
+}
+
+PT_DEV float pt_rcp(float x)
+{
+    if (__builtin_expect(in_exp_range(x, 27u, 227u), 1)) return rcp_newton(x);
+    return 1.f / x;
+}
+
+PT_DEV float pt_div(float a, float b)
+{
+    // 2^-30 <= |a|, |b| < 2^30: quotient and the exact residual a - b*q stay representable
+    if (__builtin_expect(in_exp_range(a, 97u, 157u) && in_exp_range(b, 97u, 157u), 1)) {
+        const float r = rcp_newton(b);
+        const float q = a * r;
+        const float e = __builtin_fmaf(-b, q, a);
+        return __builtin_fmaf(e, r, q);
+    }
+    return a / b;
+}
+
 struct V3 { float x, y, z; };
 
 // geometry.h:91-133: Vec / Point / Color arithmetic; `a / s` is `a * (1.f / s)`.
@@ -28,13 +84,13 @@ PT_DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 PT_DEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 PT_DEV V3 operator*(V3 a, float d) { return mk(a.x * d, a.y * d, a.z * d); }
 PT_DEV V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
-PT_DEV V3 vdiv(V3 a, float d) { const float inv = 1.f / d; return a * inv; }
+PT_DEV V3 vdiv(V3 a, float d) { const float inv = pt_rcp(d); return a * inv; }
 PT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }      // geometry.h:48-50
 PT_DEV V3 cross(V3 a, V3 b)                                                      // geometry.h:45-47
 {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-PT_DEV float length(V3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+PT_DEV float length(V3 a) { return pt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
 PT_DEV V3 normalize(V3 a) { return vdiv(a, length(a)); }                         // geometry.h:131-133
 
 // ---- counter-based RNG --------------------------------------------------------------------
@@ -87,36 +143,29 @@ PT_DEV void pt_sincosf(float x, float &s_out, float &c_out)
 }
 
 // ---- sampling -----------------------------------------------------------------------------
-// ConcentricSampleDisk, montecarlo.h:76-118
+// ConcentricSampleDisk, montecarlo.h:76-118.  The four regions are folded into selects and ONE
+// division: region 1 gives sy/r or 8 + sy/r, region 2: 2 - sx/r, region 3: 4 - sy/r, region 4:
+// 6 + sx/r; `0 + q` equals q for the positive quotient of region 1, and a - q == a + (-q).
 PT_DEV void concentric_sample_disk(float u1, float u2, float &dx, float &dy)
 {
-    float r, theta;
     const float sx = 2.f * u1 - 1.f;
     const float sy = 2.f * u2 - 1.f;
-    if (sx == 0.f && sy == 0.f) { dx = 0.f; dy = 0.f; return; }
-    if (sx >= -sy) {
-        if (sx > sy) {
-            r = sx;
-            if (sy > 0.f) theta = sy / r;
-            else          theta = 8.f + sy / r;
-        } else {
-            r = sy;
-            theta = 2.f - sx / r;
-        }
-    } else {
-        if (sx <= sy) {
-            r = -sx;
-            theta = 4.f - sy / r;
-        } else {
-            r = -sy;
-            theta = 6.f + sx / r;
-        }
-    }
+    const bool upper = sx >= -sy;            // regions 1, 2
+    const bool r1 = upper && sx > sy;
+    const bool r2 = upper && !r1;
+    const bool r3 = !upper && sx <= sy;
+    const bool use_sy = r1 || r3;            // numerator sy (else sx)
+    const float num = use_sy ? sy : sx;
+    const float r = r1 ? sx : (r2 ? sy : (r3 ? -sx : -sy));
+    const float off = r1 ? (sy > 0.f ? 0.f : 8.f) : (r2 ? 2.f : (r3 ? 4.f : 6.f));
+    const float q = pt_div(num, r);
+    float theta = (r2 || r3) ? off - q : off + q;
     theta *= PT_M_PI / 4.f;
     float s, c;
     pt_sincosf(theta, s, c);
-    dx = r * c;
-    dy = r * s;
+    const bool origin = sx == 0.f && sy == 0.f;   // montecarlo.h:85-89
+    dx = origin ? 0.f : r * c;
+    dy = origin ? 0.f : r * s;
 }
 
 // RotateByNormal, montecarlo.h:120-125 (tangent u deliberately not normalised)
@@ -134,7 +183,7 @@ PT_DEV V3 cosine_sample_hemisphere(float u1, float u2, V3 n)
     V3 ret = mk(0.f, 0.f, 0.f);
     concentric_sample_disk(u1, u2, ret.x, ret.y);
     const float e = 1.f - ret.x * ret.x - ret.y * ret.y;
-    ret.z = __builtin_sqrtf(0.f > e ? 0.f : e);
+    ret.z = pt_sqrt(0.f > e ? 0.f : e);
     return rotate_by_normal(ret, n);
 }
 
@@ -146,7 +195,7 @@ PT_DEV V3 refract(V3 wo, V3 n, float eta)
 {
     const float cost = dot(wo, n);
     const float cos2t = 1.f - eta * eta * (1.f - cost * cost);
-    return normalize(wo * eta - n * (eta * cost + __builtin_sqrtf(cos2t)));
+    return normalize(wo * eta - n * (eta * cost + pt_sqrt(cos2t)));
 }
 
 // reflectance (Fresnel), globals.h:117-126
@@ -156,7 +205,7 @@ PT_DEV float reflectance(V3 inc, V3 nor, float n1, float n2)
     const float cosI = -(dot(nor, inc));
     const float sinT2 = n * n * (1.0f - cosI * cosI);
     if (sinT2 > 1.0f) return 1.0f;
-    const float cosT = __builtin_sqrtf(1.0f - sinT2);
+    const float cosT = pt_sqrt(1.0f - sinT2);
     const float rOrth = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
     const float rPar = (n2 * cosI - n1 * cosT) / (n2 * cosI + n1 * cosT);
     return (rOrth * rOrth + rPar * rPar) / 2.0f;
@@ -202,7 +251,7 @@ PT_DEV void sphere_test(float4 s, int index, V3 o, V3 d, float &tmax, int &best)
     const float b = opx * d.x + opy * d.y + opz * d.z;
     const float det = b * b - (opx * opx + opy * opy + opz * opz) + s.w;
     if (!(det < 0.f)) {
-        const float sq = __builtin_sqrtf(det);
+        const float sq = pt_sqrt(det);
         float t = b - sq;
         if (!(t > PT_EPSILON)) t = b + sq;
         if (t > PT_EPSILON && t < tmax) { tmax = t; best = index; }

@@ -257,7 +257,68 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
     if (lane == 0 && p.ray_counter && total) atomicAdd(p.ray_counter, (unsigned long long)total);
 }
 
+// ---- arithmetic self-test kernels ---------------------------------------------------------------
+__device__ __forceinline__ float selftest_op(int op, float a, float b)
+{
+    float s, c;
+    switch (op) {
+    case 0: return pt_sqrt(a);
+    case 1: return pt_rcp(a);
+    case 2: return pt_div(a, b);
+    case 3: pt_sincosf(a, s, c); return s;
+    default: pt_sincosf(a, s, c); return c;
+    }
+}
+
+__global__ void selftest_eval_kernel(int op, const float *a, const float *b, float *out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = selftest_op(op, a[i], b ? b[i] : 0.f);
+}
+
+// Compares the short sequences with the compiler's generic IEEE expansions: every one of the
+// 2^32 bit patterns for sqrt and 1/x, 2^32 Philox-random operand pairs for a/b.
+__global__ void selftest_exhaustive_kernel(int op, unsigned long long *mismatches)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // grid covers 2^24 threads
+    uint32_t bad = 0;
+    for (uint32_t k = 0; k < 256; ++k) {
+        const uint32_t bits = (k << 24) | i;
+        float got, want;
+        if (op == 0) { const float x = __uint_as_float(bits); got = pt_sqrt(x); want = __builtin_sqrtf(x); }
+        else if (op == 1) { const float x = __uint_as_float(bits); got = pt_rcp(x); want = 1.f / x; }
+        else {
+            uint32_t r[4];
+            philox4x32_10(bits, 0u, 0u, 0x5e1f7e57u, 1u, 2u, r);
+            // exponents confined to the fast range half of the time, anything otherwise
+            float a = __uint_as_float(r[0]), b = __uint_as_float(r[1]);
+            if (r[2] & 1u) {
+                a = __uint_as_float((r[0] & 0x807fffffu) | ((100u + (r[2] >> 8) % 54u) << 23));
+                b = __uint_as_float((r[1] & 0x807fffffu) | ((100u + (r[3] >> 8) % 54u) << 23));
+            }
+            got = pt_div(a, b); want = a / b;
+        }
+        const bool both_nan = (got != got) && (want != want);
+        if (!both_nan && __float_as_uint(got) != __float_as_uint(want)) ++bad;
+    }
+    const uint32_t total = wave_sum(bad);
+    if ((threadIdx.x & 63) == 0 && total) atomicAdd(mismatches, (unsigned long long)total);
+}
+
 } // namespace
+
+hipError_t launch_selftest_eval(int op, const float *a, const float *b, float *out, uint64_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(selftest_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, op, a, b, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_exhaustive(int op, unsigned long long *mismatches, hipStream_t stream)
+{
+    hipLaunchKernelGGL(selftest_exhaustive_kernel, dim3(1u << 16), dim3(256), 0, stream, op, mismatches);
+    return hipGetLastError();
+}
 
 size_t render_lds_bytes(const RenderParams &p, bool tiled)
 {

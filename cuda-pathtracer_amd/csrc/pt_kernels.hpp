@@ -50,4 +50,10 @@ size_t render_lds_bytes(const RenderParams &p, bool tiled);
 hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled,
                          bool record, hipStream_t stream);
 
+// Arithmetic self-tests (device pointers): out[i] = op(a[i], b[i]) with the device functions the
+// trace loop uses; exhaustive comparison of the short sqrt / reciprocal / division sequences
+// against the compiler's IEEE expansions.
+hipError_t launch_selftest_eval(int op, const float *a, const float *b, float *out, uint64_t n, hipStream_t stream);
+hipError_t launch_selftest_exhaustive(int op, unsigned long long *mismatches, hipStream_t stream);
+
 } // namespace ptmi

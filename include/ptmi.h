@@ -164,6 +164,16 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
                    uint32_t iteration, int32_t *hit_ids, float *radiance, float *pixel_rgb,
                    uint64_t *ray_count);
 
+/* ---- arithmetic self-tests (no counterpart in the reference) --------------------------------
+ * The trace loop computes sqrt, 1/x and a/b with short correctly rounded sequences and sin/cos
+ * with a fixed fp32 polynomial so that the device matches a host evaluation bit for bit.
+ * pt_selftest_eval: out[i] = op(a[i], b[i]) on the device; op 0 sqrt(a), 1 1/a, 2 a/b,
+ *   3 sin(a), 4 cos(a) (b may be NULL unless op == 2).  Host pointers.
+ * pt_selftest_exhaustive: number of results that differ from the compiler's generic IEEE
+ *   expansion over all 2^32 float bit patterns (op 0, 1) or 2^32 random operand pairs (op 2). */
+int pt_selftest_eval(pt_handle h, int op, const float *a, const float *b, float *out, uint64_t n);
+int pt_selftest_exhaustive(pt_handle h, int op, uint64_t *mismatches);
+
 /* ---- host-side scene helpers (plain host code, no device needed) ------------------------- */
 
 /* Camera::Camera + UpdateParameter, camera.h:31-57,144-158. */

@@ -1,0 +1,53 @@
+// Quick A/B harness over the C ABI (no Python start-up): renders a built-in workload a few
+// times and prints time, bounces/s and an FNV-1a hash of the frame buffer, so that a kernel
+// change can be checked for speed and for bit-identical output in one short GPU call.
+//   pt_bench <scene 0|1|2> <width> <height> <iterations> <depth> <repeats> [variant] [lds_pad]
+#include "ptmi.h"
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+int main(int argc, char **argv)
+{
+    const int scene = argc > 1 ? atoi(argv[1]) : 0;
+    const uint32_t w = argc > 2 ? atoi(argv[2]) : 1920, h = argc > 3 ? atoi(argv[3]) : 1080;
+    const uint32_t iters = argc > 4 ? atoi(argv[4]) : 64;
+    const int depth = argc > 5 ? atoi(argv[5]) : 8;
+    const int repeats = argc > 6 ? atoi(argv[6]) : 3;
+    const int variant = argc > 7 ? atoi(argv[7]) : 0;
+
+    uint32_t nm = 0, ns = 0, nl = 0;
+    float eye[3], look[3], up[3], fov;
+    pt_scene_build(scene, 1, nullptr, &nm, nullptr, &ns, nullptr, &nl, eye, look, up, &fov);
+    std::vector<pt_material> m(nm); std::vector<pt_sphere> s(ns); std::vector<pt_light> l(nl);
+    pt_scene_build(scene, 1, m.data(), &nm, s.data(), &ns, l.data(), &nl, nullptr, nullptr, nullptr, nullptr);
+    pt_camera_pod cam;
+    pt_camera_init(&cam, eye, look, up, w, h, fov);
+    pt_handle hd;
+    if (pt_create(&hd, &cam, depth, 1) != PT_OK) { printf("%s\n", pt_last_error(nullptr)); return 1; }
+    if (pt_init_scene(hd, m.data(), nm, s.data(), ns, l.data(), nl) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
+    pt_set_kernel_variant(hd, variant);
+    float *buf;
+    const size_t n = (size_t)w * h * 3;
+    if (hipMalloc((void **)&buf, n * sizeof(float)) != hipSuccess) return 1;
+    std::vector<float> img(n);
+    for (int r = 0; r < repeats; ++r) {
+        pt_reset(hd); pt_reset_counters(hd);
+        const auto t0 = std::chrono::steady_clock::now();
+        if (pt_run_n(hd, buf, iters, 1) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        float ms = 0; pt_last_kernel_ms(hd, &ms);
+        uint64_t rays = 0; pt_ray_count(hd, &rays);
+        pt_read_image(hd, buf, img.data());
+        uint64_t hash = 1469598103934665603ull;
+        const unsigned char *p = (const unsigned char *)img.data();
+        for (size_t i = 0; i < n * 4; ++i) { hash ^= p[i]; hash *= 1099511628211ull; }
+        printf("scene %d %ux%u it%u d%d v%d: wall %.3f ms kernel %.3f ms  %.3f Gbounces/s  rays %llu  hash %016llx\n",
+               scene, w, h, iters, depth, variant, dt * 1e3, ms, rays / (ms * 1e-3) / 1e9,
+               (unsigned long long)rays, (unsigned long long)hash);
+    }
+    pt_destroy(hd);
+    return 0;
+}
