@@ -15,8 +15,8 @@ CSRC     := $(PKG)/csrc
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
             -fhip-fp32-correctly-rounded-divide-sqrt -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
-SRCS := $(CSRC)/pt_kernels.hip $(CSRC)/pt_api.cpp $(CSRC)/pt_scene.cpp
-HDRS := include/ptmi.h $(CSRC)/pt_kernels.hpp $(CSRC)/pt_device.hpp
+SRCS := $(CSRC)/pt_kernels.hip $(CSRC)/pt_wavefront.hip $(CSRC)/pt_api.cpp $(CSRC)/pt_scene.cpp
+HDRS := include/ptmi.h $(CSRC)/pt_kernels.hpp $(CSRC)/pt_device.hpp $(CSRC)/pt_trace.hpp
 
 all: lib oracle
 

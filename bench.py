@@ -92,11 +92,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PT_BENCH_BACKEND=gloo is a functional rehearsal of the N>1 path on a box with fewer GPUs
+    # than ranks (ranks share devices, the reduce is staged through host memory); the driver's
+    # scaling runs use the default: one GPU per rank, RCCL.
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pt = importlib.import_module("cuda-pathtracer_amd")
     sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
@@ -117,7 +125,12 @@ def main():
         tr.SetIteration(first - 1)
         tr.RunN(buf, n_it, sync=False)
         if world > 1:
-            sharding.reduce_to_root(buf, dist, 0)
+            if backend == "nccl":
+                sharding.reduce_to_root(buf, dist, 0)
+            else:
+                host = buf.cpu()
+                sharding.reduce_to_root(host, dist, 0)
+                buf.copy_(host)
             if rank == 0:
                 buf.mul_(1.0 / float(world * n_it))
 
@@ -126,6 +139,12 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def all_reduce_scalar(value, op):
+        t = torch.tensor([value], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=op)
+        return float(t.item())
 
     for _ in range(args.warmup):
         step()
@@ -143,12 +162,8 @@ def main():
     region_ms = ev0.elapsed_time(ev1)
     rays_local = tr.RayCount()
 
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    r = torch.tensor([rays_local], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-    dt_max, rays_total = float(t.item()), float(r.item())
+    dt_max = all_reduce_scalar(dt, dist.ReduceOp.MAX)
+    rays_total = all_reduce_scalar(float(rays_local), dist.ReduceOp.SUM)
 
     # Average launch duration of the render kernel: at N=1 the timed region is nothing but the
     # K launches, so the event pair around it gives it directly; with a reduce in the step the

@@ -37,6 +37,13 @@ struct pt_context {
     float *d_internal_buffer; // frame buffer owned by the library when the caller passes host memory
     hipEvent_t ev_start, ev_stop;
     bool timed;
+    // wavefront variant: queues, per-path radiance and counters, allocated on first use
+    bool wavefront;
+    WavefrontQueue wf_queue[2];
+    float *wf_radiance;
+    uint32_t *wf_counts;
+    uint32_t wf_sub_capacity;   // paths per sub-queue the buffers were sized for
+    uint64_t wf_capacity;       // paths per batch the buffers were sized for
     std::string error;
 };
 
@@ -112,6 +119,12 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->d_internal_buffer = nullptr;
     h->ev_start = h->ev_stop = nullptr;
     h->timed = false;
+    h->wavefront = false;
+    memset(h->wf_queue, 0, sizeof h->wf_queue);
+    h->wf_radiance = nullptr;
+    h->wf_counts = nullptr;
+    h->wf_sub_capacity = 0;
+    h->wf_capacity = 0;
 
     if (hipMalloc((void **)&h->d_ray_counter, sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(h->d_ray_counter, 0, sizeof(unsigned long long)) != hipSuccess ||
@@ -135,11 +148,27 @@ static void free_scene(pt_context *h)
     h->scene_ready = false;
 }
 
+static void free_wavefront(pt_context *h)
+{
+    for (int i = 0; i < 2; ++i) {
+        if (h->wf_queue[i].a) (void)hipFree(h->wf_queue[i].a);
+        if (h->wf_queue[i].b) (void)hipFree(h->wf_queue[i].b);
+        if (h->wf_queue[i].c) (void)hipFree(h->wf_queue[i].c);
+        if (h->wf_queue[i].path) (void)hipFree(h->wf_queue[i].path);
+    }
+    memset(h->wf_queue, 0, sizeof h->wf_queue);
+    if (h->wf_radiance) (void)hipFree(h->wf_radiance);
+    if (h->wf_counts) (void)hipFree(h->wf_counts);
+    h->wf_radiance = nullptr; h->wf_counts = nullptr;
+    h->wf_sub_capacity = 0; h->wf_capacity = 0;
+}
+
 int pt_destroy(pt_handle h)
 {
     if (!h) return PT_ERR_INVALID;
     (void)hipStreamSynchronize(h->stream);
     free_scene(h);
+    free_wavefront(h);
     if (h->d_ray_counter) (void)hipFree(h->d_ray_counter);
     if (h->d_internal_buffer) (void)hipFree(h->d_internal_buffer);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
@@ -253,7 +282,9 @@ int pt_set_row_bands(pt_handle h, uint32_t band_rows, uint32_t rank, uint32_t wo
 int pt_set_kernel_variant(pt_handle h, int variant)
 {
     if (!h) return PT_ERR_INVALID;
-    if (variant == 0) h->regen_min_idle = 1;
+    h->wavefront = false;
+    if (variant == PT_VARIANT_WAVEFRONT) h->wavefront = true;
+    else if (variant == 0) h->regen_min_idle = 1;
     else if (variant == 1) h->regen_min_idle = 64;
     else if (variant >= 2 && variant <= 64) h->regen_min_idle = variant; // experimental: idle-lane threshold
     else return fail(h, PT_ERR_INVALID, "pt_set_kernel_variant: unknown variant %d", variant);
@@ -270,24 +301,109 @@ int pt_reset(pt_handle h)
 
 uint32_t pt_iteration(pt_handle h) { return h ? h->iteration : 0; }
 
+static void fill_camera(const pt_context *h, CameraParams &c)
+{
+    for (int i = 0; i < 3; ++i) {
+        c.pos[i] = h->camera.pos[i];
+        c.pxx[i] = h->camera.px_x[i];
+        c.pxy[i] = h->camera.px_y[i];
+        c.first[i] = h->camera.first_ray_dir[i];
+    }
+    c.width = h->camera.width; c.height = h->camera.height;
+}
+
+static void fill_scene(const pt_context *h, SceneParams &s)
+{
+    s.sph = h->d_sph; s.aux = h->d_aux; s.mat = h->d_mat; s.mat_type = h->d_mat_type; s.light = h->d_light;
+    s.n_prims = h->n_prims; s.n_mats = h->n_mats; s.n_lights = h->n_lights;
+}
+
 static void fill_params(const pt_context *h, RenderParams &p)
 {
     memset(&p, 0, sizeof p);
-    for (int i = 0; i < 3; ++i) {
-        p.cam_pos[i] = h->camera.pos[i];
-        p.cam_pxx[i] = h->camera.px_x[i];
-        p.cam_pxy[i] = h->camera.px_y[i];
-        p.cam_first[i] = h->camera.first_ray_dir[i];
-    }
-    p.width = h->camera.width; p.height = h->camera.height;
-    p.sph = h->d_sph; p.aux = h->d_aux; p.mat = h->d_mat; p.mat_type = h->d_mat_type; p.light = h->d_light;
-    p.n_prims = h->n_prims; p.n_mats = h->n_mats; p.n_lights = h->n_lights;
+    fill_camera(h, p.cam);
+    fill_scene(h, p.scene);
     p.seed = h->seed;
     p.max_bounces = h->max_bounces;
     p.regen_min_idle = h->regen_min_idle;
 }
 
 static uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// Paths per wavefront batch the queues are sized for (about 4 GiB of queues + radiance).
+static const uint64_t kWfTargetPaths = 32ull << 20;
+
+// Wavefront variant: batches of whole iterations; per batch one launch per bounce + a resolve.
+static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
+{
+    if (h->band_world > 1) return fail(h, PT_ERR_STATE, "the wavefront variant does not support row bands");
+    const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
+    if (h->iteration + (uint64_t)n_iterations >= (1u << 30))
+        return fail(h, PT_ERR_INVALID, "wavefront variant: iteration numbers must stay below 2^30");
+    uint32_t batch_it = (uint32_t)(kWfTargetPaths / paths_per_it);
+    if (batch_it < 1) batch_it = 1;
+    if (batch_it > n_iterations) batch_it = n_iterations;
+    const uint64_t capacity = paths_per_it * batch_it;
+    const uint64_t blocks = (capacity + 255) / 256;
+    const uint64_t sub_cap64 = (blocks + kWfSubQueues - 1) / kWfSubQueues * 256;
+    if (sub_cap64 > 0xffffff00ull) return fail(h, PT_ERR_INVALID, "wavefront variant: image too large");
+    const uint32_t sub_cap = (uint32_t)sub_cap64;
+    const size_t counts_bytes = (size_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
+
+    if (capacity > h->wf_capacity || sub_cap > h->wf_sub_capacity || !h->wf_counts) {
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        free_wavefront(h);
+        const size_t slots = (size_t)sub_cap * kWfSubQueues;
+        for (int i = 0; i < 2; ++i) {
+            PT_HIP(h, hipMalloc((void **)&h->wf_queue[i].a, slots * sizeof(float4)));
+            PT_HIP(h, hipMalloc((void **)&h->wf_queue[i].b, slots * sizeof(float4)));
+            PT_HIP(h, hipMalloc((void **)&h->wf_queue[i].c, slots * sizeof(float4)));
+            PT_HIP(h, hipMalloc((void **)&h->wf_queue[i].path, slots * sizeof(uint2)));
+        }
+        PT_HIP(h, hipMalloc((void **)&h->wf_radiance, capacity * 3 * sizeof(float)));
+        PT_HIP(h, hipMalloc((void **)&h->wf_counts, counts_bytes));
+        h->wf_capacity = capacity;
+        h->wf_sub_capacity = sub_cap;
+    }
+
+    WavefrontParams p;
+    memset(&p, 0, sizeof p);
+    fill_camera(h, p.cam);
+    fill_scene(h, p.scene);
+    p.seed = h->seed;
+    p.max_bounces = h->max_bounces;
+    p.sub_capacity = h->wf_sub_capacity;
+    p.counts = h->wf_counts;
+    p.path_radiance = h->wf_radiance;
+    p.accum_mode = h->accum_mode;
+    p.buffer = dbuf;
+    p.ray_counter = h->d_ray_counter;
+    const bool tiled = p.scene.n_prims > kMaxResidentSpheres;
+
+    PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
+    uint32_t done = 0;
+    while (done < n_iterations) {
+        const uint32_t n = n_iterations - done < batch_it ? n_iterations - done : batch_it;
+        p.first_iteration = h->iteration + done + 1;
+        p.n_iterations = n;
+        p.overwrite = h->accum_mode == PT_ACCUM_RUNNING_MEAN ? (p.first_iteration == 1)
+                                                             : ((h->fresh && done == 0) ? 1 : 0);
+        PT_HIP(h, hipMemsetAsync(h->wf_counts, 0, counts_bytes, h->stream));
+        for (int b = 0; b <= h->max_bounces; ++b) {
+            p.bounce = b;
+            p.out = h->wf_queue[b & 1];
+            p.in = h->wf_queue[(b & 1) ^ 1];
+            PT_HIP(h, launch_wavefront_step(p, tiled, h->stream));
+        }
+        PT_HIP(h, launch_wavefront_resolve(p, h->stream));
+        done += n;
+    }
+    PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
+    h->timed = true;
+    h->iteration += n_iterations;
+    h->fresh = false;
+    return PT_OK;
+}
 
 // Enqueue n iterations on the handle's stream.
 static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
@@ -296,10 +412,11 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
     if (!dbuf) return fail(h, PT_ERR_INVALID, "render: buffer is NULL");
     if (n_iterations == 0) return PT_OK;
     if (h->iteration > 0xffffffffu - n_iterations) return fail(h, PT_ERR_INVALID, "iteration counter overflow");
+    if (h->wavefront) return enqueue_wavefront(h, dbuf, n_iterations);
 
     RenderParams p;
     fill_params(h, p);
-    p.x0 = 0; p.y0 = 0; p.x1 = p.width; p.y1 = p.height;
+    p.x0 = 0; p.y0 = 0; p.x1 = p.cam.width; p.y1 = p.cam.height;
     p.first_iteration = h->iteration + 1;
     p.n_iterations = n_iterations;
     p.accum_mode = h->accum_mode;
@@ -309,18 +426,18 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
 
     uint32_t grid_y;
     if (h->band_world > 1) {
-        const uint32_t n_bands = div_up(p.height, h->band_rows);
+        const uint32_t n_bands = div_up(p.cam.height, h->band_rows);
         const uint32_t owned = n_bands > h->band_rank ? div_up(n_bands - h->band_rank, h->band_world) : 0;
         p.band_rows = h->band_rows; p.band_rank = h->band_rank; p.band_world = h->band_world;
         grid_y = owned * (h->band_rows / 16);
     } else {
-        p.band_rows = div_up(p.height, 16) * 16; p.band_rank = 0; p.band_world = 1;
+        p.band_rows = div_up(p.cam.height, 16) * 16; p.band_rank = 0; p.band_world = 1;
         grid_y = p.band_rows / 16;
     }
-    const bool tiled = p.n_prims > kMaxResidentSpheres;
+    const bool tiled = p.scene.n_prims > kMaxResidentSpheres;
     if (grid_y > 0) {
         PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
-        PT_HIP(h, launch_render(p, div_up(p.width, 16), grid_y, tiled, false, h->stream));
+        PT_HIP(h, launch_render(p, div_up(p.cam.width, 16), grid_y, tiled, false, h->stream));
         PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
         h->timed = true;
     }
@@ -434,7 +551,7 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
         p.buffer = nullptr;
         p.ray_counter = d_cnt;
         p.hit_ids = d_hits; p.path_rad = d_rad; p.pixel_rgb = d_rgb;
-        const bool tiled = p.n_prims > kMaxResidentSpheres;
+        const bool tiled = p.scene.n_prims > kMaxResidentSpheres;
         DBG_HIP(launch_render(p, div_up(x1 - x0, 16), p.band_rows / 16, tiled, true, h->stream));
     }
     if (hit_ids) DBG_HIP(hipMemcpyAsync(hit_ids, d_hits, hit_elems * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));

@@ -201,13 +201,13 @@ PT_DEV V3 refract(V3 wo, V3 n, float eta)
 // reflectance (Fresnel), globals.h:117-126
 PT_DEV float reflectance(V3 inc, V3 nor, float n1, float n2)
 {
-    const float n = n1 / n2;
+    const float n = pt_div(n1, n2);
     const float cosI = -(dot(nor, inc));
     const float sinT2 = n * n * (1.0f - cosI * cosI);
     if (sinT2 > 1.0f) return 1.0f;
     const float cosT = pt_sqrt(1.0f - sinT2);
-    const float rOrth = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
-    const float rPar = (n2 * cosI - n1 * cosT) / (n2 * cosI + n1 * cosT);
+    const float rOrth = pt_div(n1 * cosI - n2 * cosT, n1 * cosI + n2 * cosT);
+    const float rPar = pt_div(n2 * cosI - n1 * cosT, n2 * cosI + n1 * cosT);
     return (rOrth * rOrth + rPar * rPar) / 2.0f;
 }
 
@@ -231,7 +231,7 @@ PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &
         else                  { n1 = coef; n2 = 1.f; nnor = -n; }
         const float refl = reflectance(wo, nnor, n1, n2);
         if (su < refl) wi = reflect(wo, nnor);
-        else           wi = refract(wo, nnor, n1 / n2);
+        else           wi = refract(wo, nnor, pt_div(n1, n2));
         f = color;
         pdf = 1.f;
     } else {

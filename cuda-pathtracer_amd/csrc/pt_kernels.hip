@@ -16,44 +16,11 @@
 //
 // Scene data: spheres as float4 (cx, cy, cz, r*r) read as wave-uniform LDS broadcasts.  Small
 // scenes are staged once per workgroup; larger ones stream through a 1024-sphere LDS tile.
-#include "pt_kernels.hpp"
-#include "pt_device.hpp"
+#include "pt_trace.hpp"
 
 namespace ptmi {
 
 namespace {
-
-constexpr int kBlockThreads = 256;
-
-// Wave-wide sum of a 32-bit counter (wave64), result valid in every lane.
-PT_DEV uint32_t wave_sum(uint32_t v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-struct LdsScene {
-    const float4 *sph;   // [n_prims] or one tile
-    const float4 *aux;   // (1/radius, materialId bits, lightId bits, radius)
-    const float4 *mat;   // (r, g, b, coef)
-    const int *mat_type;
-    const float4 *light; // (r, g, b, -)
-};
-
-// Scan `count` spheres that sit in LDS starting at global index `base`.
-PT_DEV void scan_lds(const float4 *sph, int base, int count, V3 o, V3 d, float &tmax, int &best)
-{
-    int i = 0;
-    for (; i + 4 <= count; i += 4) {
-        const float4 s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
-        sphere_test(s0, base + i, o, d, tmax, best);
-        sphere_test(s1, base + i + 1, o, d, tmax, best);
-        sphere_test(s2, base + i + 2, o, d, tmax, best);
-        sphere_test(s3, base + i + 3, o, d, tmax, best);
-    }
-    for (; i < count; ++i) sphere_test(sph[i], base + i, o, d, tmax, best);
-}
 
 template <bool TILED, bool RECORD>
 __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParams p)
@@ -62,29 +29,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-
-    // ---- stage the scene -----------------------------------------------------------------
-    LdsScene sc;
-    float4 *lds_sph = reinterpret_cast<float4 *>(lds_raw);
-    if (!TILED) {
-        float4 *lds_aux = lds_sph + p.n_prims;
-        float4 *lds_mat = lds_aux + p.n_prims;
-        float4 *lds_light = lds_mat + p.n_mats;
-        int *lds_type = reinterpret_cast<int *>(lds_light + p.n_lights);
-        for (uint32_t i = tid; i < p.n_prims; i += kBlockThreads) {
-            lds_sph[i] = p.sph[i];
-            lds_aux[i] = p.aux[i];
-        }
-        for (uint32_t i = tid; i < p.n_mats; i += kBlockThreads) {
-            lds_mat[i] = p.mat[i];
-            lds_type[i] = p.mat_type[i];
-        }
-        for (uint32_t i = tid; i < p.n_lights; i += kBlockThreads) lds_light[i] = p.light[i];
-        __syncthreads();
-        sc.sph = lds_sph; sc.aux = lds_aux; sc.mat = lds_mat; sc.mat_type = lds_type; sc.light = lds_light;
-    } else {
-        sc.sph = lds_sph; sc.aux = p.aux; sc.mat = p.mat; sc.mat_type = p.mat_type; sc.light = p.light;
-    }
+    const SceneView sc = stage_scene<TILED>(p.scene, lds_raw, tid);
 
     // ---- pixel owned by this lane ----------------------------------------------------------
     // blockIdx.y enumerates the 16-row block rows of the bands this instance owns.
@@ -95,13 +40,10 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
     const uint32_t x = p.x0 + blockIdx.x * 16u + (uint32_t)((wave & 1) * 8 + (lane & 7));
     const uint32_t y = yb + (uint32_t)((wave >> 1) * 8 + (lane >> 3));
     const bool valid = x < p.x1 && y < p.y1;
-    const uint32_t pix = y * p.width + x;
+    const uint32_t pix = y * p.cam.width + x;
     const uint32_t rect_pix = (y - p.y0) * (p.x1 - p.x0) + (x - p.x0);
 
-    const V3 cam_pos = mk(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
-    const V3 cam_pxx = mk(p.cam_pxx[0], p.cam_pxx[1], p.cam_pxx[2]);
-    const V3 cam_pxy = mk(p.cam_pxy[0], p.cam_pxy[1], p.cam_pxy[2]);
-    const V3 cam_first = mk(p.cam_first[0], p.cam_first[1], p.cam_first[2]);
+    const V3 cam_pos = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
     const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
     const int mb = p.max_bounces;
 
@@ -131,15 +73,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
             want = want && idle >= p.regen_min_idle;
         }
         if (want) {
-            // CameraSamples (pathtracer.cu:34-48) + Camera::GenerateRay (camera.h:66-72)
-            uint32_t r[4];
-            philox4x32_10(pix, it, (uint32_t)(sub >> 1), STREAM_CAMERA, k0, k1, r);
-            const float ju = u01((sub & 1) ? r[2] : r[0]) * ((sub & 1) ? 0.5f : -0.5f);
-            const float jv = u01((sub & 1) ? r[3] : r[1]) * ((sub & 2) ? 0.5f : -0.5f);
-            const float sx = (float)(int)x + ju;
-            const float sy = (float)(int)y + jv;
             o = cam_pos;
-            d = normalize((cam_first - cam_pxy * sy) + cam_pxx * sx);
+            d = camera_ray(p.cam, x, y, pix, it, sub, k0, k1);
             T = mk(1.f, 1.f, 1.f);
             L = mk(0.f, 0.f, 0.f);
             b = 0;
@@ -151,20 +86,9 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
             if (!__any(alive)) break;
         }
 
-        // ---- Intersect (scene.h:71-94) ---------------------------------------------------------
-        float tmax = PT_INF;
-        int best = -1;
-        if (TILED) {
-            for (uint32_t base = 0; base < p.n_prims; base += kTileSpheres) {
-                const uint32_t count = min(kTileSpheres, p.n_prims - base);
-                __syncthreads();
-                for (uint32_t i = tid; i < count; i += kBlockThreads) lds_sph[i] = p.sph[base + i];
-                __syncthreads();
-                if (alive) scan_lds(lds_sph, (int)base, (int)count, o, d, tmax, best);
-            }
-        } else {
-            if (alive) scan_lds(sc.sph, 0, (int)p.n_prims, o, d, tmax, best);
-        }
+        float tmax;
+        int best;
+        intersect_scene<TILED>(p.scene, sc, lds_raw, tid, alive, o, d, tmax, best);
 
         if (alive) {
             ++nrays;
@@ -174,46 +98,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
             }
             bool end = true;
             if (best >= 0) {
-                // hit point and normal: scene.h:86-87, primitive.h:74
-                const float4 s = TILED ? p.sph[best] : sc.sph[best];
-                const float4 a = sc.aux[best];
-                const V3 P = o + d * tmax;
-                const V3 n = (P - mk(s.x, s.y, s.z)) * a.x;
-                const V3 wo = d;
-                const uint32_t mat_id = __float_as_uint(a.y);
-                const int light_id = __float_as_int(a.z);
-
-                // emission on every light hit: pathtracer.cu:134-137, Light::L light.h:43-45
-                if (light_id > -1) {
-                    const float4 li = sc.light[light_id];
-                    const V3 le = dot(n, -wo) > 0.f ? mk(li.x, li.y, li.z) : mk(0.f, 0.f, 0.f);
-                    L = L + T * le;
-                }
-
-                uint32_t r[4];
-                philox4x32_10(pix, it, (uint32_t)b, STREAM_PATH, k0, k1, r);
-                const float4 m = sc.mat[mat_id];
-                const int mtype = sc.mat_type[mat_id];
-                V3 wi;
-                float pdf;
-                const V3 f = sample_material(mtype, mk(m.x, m.y, m.z), m.w, wo, wi, pdf, n,
-                                             u01(r[0]), u01(r[1]));
-                // pathtracer.cu:146-161
-                if (!((f.x == 0.f && f.y == 0.f && f.z == 0.f) || pdf == 0.f)) {
-                    T = T * vdiv(f * __builtin_fabsf(dot(wi, n)), pdf);
-                    o = P;
-                    d = wi;
-                    end = false;
-                    if (b > 3) {
-                        const float gb = T.y > T.z ? T.y : T.z;   // Color::Max, geometry.h:474
-                        const float mx = T.x > gb ? T.x : gb;
-                        const float q = .5f < mx ? .5f : mx;      // min macro, globals.h:66
-                        if (u01(r[2]) > q) end = true;
-                        else T = vdiv(T, q);
-                    }
-                    if (b == mb) end = true;
-                    ++b;
-                }
+                const float4 s = TILED ? p.scene.sph[best] : sc.sph[best];
+                end = shade_bounce(sc, s, best, tmax, pix, it, k0, k1, mb, o, d, T, L, b);
             }
             if (end) {
                 if (RECORD) {
@@ -225,20 +111,12 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
                 c = c + L;
                 alive = false;
                 if (++sub == 4) {
-                    // RenderKernel, pathtracer.cu:101-109
-                    c = vdiv(c, 4.f);
-                    if (p.accum_mode == 0) {
-                        const float inv_it = 1.f / (float)it;
-                        const float w = (float)(it - 1);
-                        acc = mk((acc.x * w + c.x) * inv_it, (acc.y * w + c.y) * inv_it,
-                                 (acc.z * w + c.z) * inv_it);
-                    } else {
-                        acc = acc + c;
-                    }
+                    V3 cpix;
+                    acc = accumulate_pixel(acc, c, it, p.accum_mode, &cpix);
                     if (RECORD) {
                         if (p.pixel_rgb) {
                             float *pr = p.pixel_rgb + (size_t)rect_pix * 3;
-                            pr[0] = c.x; pr[1] = c.y; pr[2] = c.z;
+                            pr[0] = cpix.x; pr[1] = cpix.y; pr[2] = cpix.z;
                         }
                     }
                     c = mk(0.f, 0.f, 0.f);
@@ -320,18 +198,18 @@ hipError_t launch_selftest_exhaustive(int op, unsigned long long *mismatches, hi
     return hipGetLastError();
 }
 
-size_t render_lds_bytes(const RenderParams &p, bool tiled)
+size_t scene_lds_bytes(const SceneParams &s, bool tiled)
 {
     if (tiled) return (size_t)kTileSpheres * sizeof(float4);
-    return (size_t)p.n_prims * 2 * sizeof(float4) + (size_t)p.n_mats * (sizeof(float4) + sizeof(int)) +
-           (size_t)p.n_lights * sizeof(float4);
+    return (size_t)s.n_prims * 2 * sizeof(float4) + (size_t)s.n_mats * (sizeof(float4) + sizeof(int)) +
+           (size_t)s.n_lights * sizeof(float4);
 }
 
 hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled,
                          bool record, hipStream_t stream)
 {
     const dim3 grid(grid_x, grid_y), block(kBlockThreads);
-    const size_t lds = render_lds_bytes(p, tiled);
+    const size_t lds = scene_lds_bytes(p.scene, tiled);
     if (tiled) {
         if (record) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, lds, stream, p);
         else        hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, stream, p);

@@ -7,27 +7,35 @@
 
 namespace ptmi {
 
-// Spheres per LDS tile of the streaming (large-scene) kernel: 1024 x 16 B = 16 KiB.
+// Spheres per LDS tile of the streaming (large-scene) kernels: 1024 x 16 B = 16 KiB.
 constexpr uint32_t kTileSpheres = 1024;
 // Scenes up to this many spheres are staged in LDS once per workgroup
 // (32 B per sphere -> 16 KiB at the limit).
 constexpr uint32_t kMaxResidentSpheres = 512;
 
-// Passed by value as the kernel argument (wave-uniform, lives in SGPRs).
-struct RenderParams {
-    // camera: what Camera::GenerateRay reads (camera.h:66-72)
-    float cam_pos[3], cam_pxx[3], cam_pxy[3], cam_first[3];
+// What Camera::GenerateRay reads (camera.h:66-72).
+struct CameraParams {
+    float pos[3], pxx[3], pxy[3], first[3];
     uint32_t width, height;
-    // pixel rectangle [x0,x1) x [y0,y1) and the row-band ownership inside it
-    uint32_t x0, y0, x1, y1;
-    uint32_t band_rows, band_rank, band_world;
-    // scene, SoA in device memory
+};
+
+// Scene, SoA in device memory.
+struct SceneParams {
     const float4 *sph;   // (cx, cy, cz, radius*radius)
     const float4 *aux;   // (1/radius, materialId bits, lightId bits, radius)
     const float4 *mat;   // (r, g, b, coef)
     const int *mat_type; // material.h:25
     const float4 *light; // (r, g, b, -) intensity
     uint32_t n_prims, n_mats, n_lights;
+};
+
+// Megakernel argument, passed by value (wave-uniform, lives in SGPRs).
+struct RenderParams {
+    CameraParams cam;
+    SceneParams scene;
+    // pixel rectangle [x0,x1) x [y0,y1) and the row-band ownership inside it
+    uint32_t x0, y0, x1, y1;
+    uint32_t band_rows, band_rank, band_world;
     // sampling
     uint64_t seed;
     int max_bounces;
@@ -44,11 +52,47 @@ struct RenderParams {
     float *pixel_rgb;                  // debug: [rect pixel][3]
 };
 
-size_t render_lds_bytes(const RenderParams &p, bool tiled);
+size_t scene_lds_bytes(const SceneParams &s, bool tiled);
 
 // grid_x x grid_y workgroups of 256 threads, each a 16x16 pixel tile.
 hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled,
                          bool record, hipStream_t stream);
+
+// ---- wavefront (path-compaction) variant ------------------------------------------------------
+// A batch holds n_iterations x width x height x 4 paths.  Every bounce is one kernel launch over
+// a compacted queue of live paths in device memory; finished paths leave their radiance in
+// `path_radiance`, which wf_resolve folds into the frame buffer in the reference's order.
+constexpr uint32_t kWfSubQueues = 64;     // independent sub-queues (one compaction counter each)
+constexpr uint32_t kWfCountStride = 32;   // uint32 per counter: every counter on its own 128-B line
+
+struct WavefrontQueue {   // [kWfSubQueues][sub_capacity]
+    float4 *a;        // (ox, oy, oz, dx)
+    float4 *b;        // (dy, dz, Tx, Ty)
+    float4 *c;        // (Tz, Lx, Ly, Lz)
+    uint2 *path;      // (pixel index, iteration << 2 | sub-sample)
+};
+
+struct WavefrontParams {
+    CameraParams cam;
+    SceneParams scene;
+    uint64_t seed;
+    int max_bounces;
+    uint32_t first_iteration;   // of the batch
+    uint32_t n_iterations;      // in the batch
+    int bounce;                 // bounce index handled by this launch
+    WavefrontQueue in, out;     // in is unused for bounce 0 (camera rays are generated)
+    uint32_t sub_capacity;      // paths per sub-queue, a multiple of 256
+    uint32_t *counts;           // [max_bounces + 2][kWfSubQueues][kWfCountStride]: paths alive in
+                                // sub-queue q entering bounce k
+    float *path_radiance;       // [paths][3]
+    // resolve
+    int accum_mode, overwrite;
+    float *buffer;
+    unsigned long long *ray_counter;
+};
+
+hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream_t stream);
+hipError_t launch_wavefront_resolve(const WavefrontParams &p, hipStream_t stream);
 
 // Arithmetic self-tests (device pointers): out[i] = op(a[i], b[i]) with the device functions the
 // trace loop uses; exhaustive comparison of the short sqrt / reciprocal / division sequences

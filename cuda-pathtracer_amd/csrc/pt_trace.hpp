@@ -1,0 +1,173 @@
+// Pieces of the trace loop shared by the megakernel (pt_kernels.hip) and the wavefront kernels
+// (pt_wavefront.hip): scene staging in LDS, the nearest-hit scan, camera-ray generation and the
+// shading of one bounce.  Both kernel families call the same functions, so their results are
+// bit-identical by construction.
+#pragma once
+
+#include "pt_device.hpp"
+#include "pt_kernels.hpp"
+
+namespace ptmi {
+
+constexpr int kBlockThreads = 256;
+
+// Wave-wide sum of a 32-bit counter (wave64), result valid in every lane.
+PT_DEV uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct SceneView {
+    const float4 *sph;   // LDS: all spheres (resident) or the current tile (streaming)
+    const float4 *aux;   // (1/radius, materialId bits, lightId bits, radius)
+    const float4 *mat;   // (r, g, b, coef)
+    const int *mat_type;
+    const float4 *light; // (r, g, b, -)
+};
+
+// Resident scenes: copy spheres, aux, materials and lights into LDS (one barrier inside).
+// Streaming scenes: only the sphere tile lives in LDS, the rest is read from global memory.
+template <bool TILED>
+PT_DEV SceneView stage_scene(const SceneParams &p, unsigned char *lds_raw, int tid)
+{
+    SceneView sc;
+    float4 *lds_sph = reinterpret_cast<float4 *>(lds_raw);
+    if (!TILED) {
+        float4 *lds_aux = lds_sph + p.n_prims;
+        float4 *lds_mat = lds_aux + p.n_prims;
+        float4 *lds_light = lds_mat + p.n_mats;
+        int *lds_type = reinterpret_cast<int *>(lds_light + p.n_lights);
+        for (uint32_t i = tid; i < p.n_prims; i += kBlockThreads) {
+            lds_sph[i] = p.sph[i];
+            lds_aux[i] = p.aux[i];
+        }
+        for (uint32_t i = tid; i < p.n_mats; i += kBlockThreads) {
+            lds_mat[i] = p.mat[i];
+            lds_type[i] = p.mat_type[i];
+        }
+        for (uint32_t i = tid; i < p.n_lights; i += kBlockThreads) lds_light[i] = p.light[i];
+        __syncthreads();
+        sc.sph = lds_sph; sc.aux = lds_aux; sc.mat = lds_mat; sc.mat_type = lds_type; sc.light = lds_light;
+    } else {
+        sc.sph = lds_sph; sc.aux = p.aux; sc.mat = p.mat; sc.mat_type = p.mat_type; sc.light = p.light;
+    }
+    return sc;
+}
+
+// Scan `count` spheres that sit in LDS starting at global index `base` (index order).
+PT_DEV void scan_lds(const float4 *sph, int base, int count, V3 o, V3 d, float &tmax, int &best)
+{
+    int i = 0;
+    for (; i + 4 <= count; i += 4) {
+        const float4 s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
+        sphere_test(s0, base + i, o, d, tmax, best);
+        sphere_test(s1, base + i + 1, o, d, tmax, best);
+        sphere_test(s2, base + i + 2, o, d, tmax, best);
+        sphere_test(s3, base + i + 3, o, d, tmax, best);
+    }
+    for (; i < count; ++i) sphere_test(sph[i], base + i, o, d, tmax, best);
+}
+
+// Intersect (scene.h:71-94).  With TILED every thread of the workgroup must call it (barriers);
+// `active` masks the lanes that actually carry a ray.
+template <bool TILED>
+PT_DEV void intersect_scene(const SceneParams &p, const SceneView &sc, unsigned char *lds_raw, int tid,
+                            bool active, V3 o, V3 d, float &tmax, int &best)
+{
+    tmax = PT_INF;
+    best = -1;
+    if (TILED) {
+        float4 *lds_sph = reinterpret_cast<float4 *>(lds_raw);
+        for (uint32_t base = 0; base < p.n_prims; base += kTileSpheres) {
+            const uint32_t count = min(kTileSpheres, p.n_prims - base);
+            __syncthreads();
+            for (uint32_t i = tid; i < count; i += kBlockThreads) lds_sph[i] = p.sph[base + i];
+            __syncthreads();
+            if (active) scan_lds(lds_sph, (int)base, (int)count, o, d, tmax, best);
+        }
+    } else {
+        if (active) scan_lds(sc.sph, 0, (int)p.n_prims, o, d, tmax, best);
+    }
+}
+
+// CameraSamples (pathtracer.cu:34-48) + Camera::GenerateRay (camera.h:66-72) for sub-sample
+// `sub` of pixel (x, y), iteration `it`.  Returns the normalised direction.
+PT_DEV V3 camera_ray(const CameraParams &cam, uint32_t x, uint32_t y, uint32_t pix, uint32_t it, int sub,
+                     uint32_t k0, uint32_t k1)
+{
+    uint32_t r[4];
+    philox4x32_10(pix, it, (uint32_t)(sub >> 1), STREAM_CAMERA, k0, k1, r);
+    const float ju = u01((sub & 1) ? r[2] : r[0]) * ((sub & 1) ? 0.5f : -0.5f);
+    const float jv = u01((sub & 1) ? r[3] : r[1]) * ((sub & 2) ? 0.5f : -0.5f);
+    const float sx = (float)(int)x + ju;
+    const float sy = (float)(int)y + jv;
+    const V3 first = mk(cam.first[0], cam.first[1], cam.first[2]);
+    const V3 pxx = mk(cam.pxx[0], cam.pxx[1], cam.pxx[2]);
+    const V3 pxy = mk(cam.pxy[0], cam.pxy[1], cam.pxy[2]);
+    return normalize((first - pxy * sy) + pxx * sx);
+}
+
+// One iteration of the loop in Trace (pathtracer.cu:125-168) for a ray that hit sphere `best`
+// at distance t: emission, BSDF sample, throughput, Russian roulette, depth limit.  `s` is the
+// hit sphere's (cx, cy, cz, r*r).  Updates o, d, T, L and increments b when the path goes on;
+// returns true when the path ends.
+PT_DEV bool shade_bounce(const SceneView &sc, float4 s, int best, float t, uint32_t pix, uint32_t it,
+                         uint32_t k0, uint32_t k1, int mb, V3 &o, V3 &d, V3 &T, V3 &L, int &b)
+{
+    // hit point and normal: scene.h:86-87, primitive.h:74
+    const float4 a = sc.aux[best];
+    const V3 P = o + d * t;
+    const V3 n = (P - mk(s.x, s.y, s.z)) * a.x;
+    const V3 wo = d;
+    const uint32_t mat_id = __float_as_uint(a.y);
+    const int light_id = __float_as_int(a.z);
+
+    // emission on every light hit: pathtracer.cu:134-137, Light::L light.h:43-45
+    if (light_id > -1) {
+        const float4 li = sc.light[light_id];
+        const V3 le = dot(n, -wo) > 0.f ? mk(li.x, li.y, li.z) : mk(0.f, 0.f, 0.f);
+        L = L + T * le;
+    }
+
+    uint32_t r[4];
+    philox4x32_10(pix, it, (uint32_t)b, STREAM_PATH, k0, k1, r);
+    const float4 m = sc.mat[mat_id];
+    const int mtype = sc.mat_type[mat_id];
+    V3 wi;
+    float pdf;
+    const V3 f = sample_material(mtype, mk(m.x, m.y, m.z), m.w, wo, wi, pdf, n, u01(r[0]), u01(r[1]));
+    // pathtracer.cu:146-161
+    if ((f.x == 0.f && f.y == 0.f && f.z == 0.f) || pdf == 0.f) return true;
+    T = T * vdiv(f * __builtin_fabsf(dot(wi, n)), pdf);
+    o = P;
+    d = wi;
+    bool end = false;
+    if (b > 3) {
+        const float gb = T.y > T.z ? T.y : T.z;   // Color::Max, geometry.h:474
+        const float mx = T.x > gb ? T.x : gb;
+        const float q = .5f < mx ? .5f : mx;      // min macro, globals.h:66
+        if (u01(r[2]) > q) end = true;
+        else T = vdiv(T, q);
+    }
+    if (b == mb) end = true;
+    ++b;
+    return end;
+}
+
+// RenderKernel's accumulation (pathtracer.cu:101-109): c is the in-order sum of the pixel's four
+// path radiances; acc the pixel's frame-buffer value.
+PT_DEV V3 accumulate_pixel(V3 acc, V3 c_sum, uint32_t it, int accum_mode, V3 *c_out = nullptr)
+{
+    const V3 c = c_sum * 0.25f;   // c /= 4.f is c * (1.f / 4.f), exactly 0.25
+    if (c_out) *c_out = c;
+    if (accum_mode == 0) {
+        const float inv_it = pt_rcp((float)it);
+        const float w = (float)(it - 1);
+        return mk((acc.x * w + c.x) * inv_it, (acc.y * w + c.y) * inv_it, (acc.z * w + c.z) * inv_it);
+    }
+    return acc + c;
+}
+
+} // namespace ptmi

@@ -1,0 +1,171 @@
+// Wavefront (path-compaction) variant of the trace loop for gfx950.
+//
+// The megakernel (pt_kernels.hip) keeps a path in one lane from camera ray to termination.
+// Here every bounce is its own launch over a compacted queue of live paths in device memory:
+// each launch reads a path's state, runs one Intersect + one bounce of shading (the same device
+// functions as the megakernel, so results are bit-identical) and either stores the path's final
+// radiance or appends the continued path to the next queue.  All lanes of a wave start every
+// launch alive and at the same bounce; the price is ~112 B of queue traffic per path-bounce
+// and one launch per bounce.  pt_set_kernel_variant(h, PT_VARIANT_WAVEFRONT) selects it; which
+// variant is faster depends on the scene (see the profiles).
+//
+// Queue layout: 64 sub-queues, each with its own counter on its own 128-byte line, so that the
+// compaction atomics (one per wave) do not serialise on a single address.  Survivors of
+// sub-queue q stay in sub-queue q, hence no sub-queue can outgrow its capacity.
+#include "pt_trace.hpp"
+
+namespace ptmi {
+
+namespace {
+
+// counts[bounce][q * kCountStride]: number of paths alive in sub-queue q entering `bounce`
+PT_DEV uint32_t *count_ptr(uint32_t *counts, int bounce, uint32_t q)
+{
+    return counts + ((size_t)bounce * kWfSubQueues + q) * kWfCountStride;
+}
+
+template <bool TILED>
+__global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontParams p)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t q = blockIdx.x;                 // sub-queue
+    const uint32_t n_pix = p.cam.width * p.cam.height;
+    const uint64_t n_paths = (uint64_t)p.n_iterations * n_pix * 4;
+
+    // Number of 256-path chunks of this sub-queue.  Bounce 0 has no input queue: path i of the
+    // batch is (iteration offset, pixel, sub) in that order, and chunk c of sub-queue q is the
+    // 256 paths starting at (c * 64 + q) * 256.
+    uint32_t n_items = 0, n_chunks;
+    if (p.bounce == 0) {
+        const uint64_t blocks = (n_paths + kBlockThreads - 1) / kBlockThreads;
+        n_chunks = (uint32_t)((blocks + kWfSubQueues - 1 - q) / kWfSubQueues);
+    } else {
+        n_items = *count_ptr(p.counts, p.bounce, q);
+        n_chunks = (n_items + kBlockThreads - 1) / kBlockThreads;
+    }
+    if (blockIdx.y >= n_chunks) return;            // uniform for the whole workgroup
+
+    const SceneView sc = stage_scene<TILED>(p.scene, lds_raw, tid);
+    const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
+
+    for (uint32_t chunk = blockIdx.y; chunk < n_chunks; chunk += gridDim.y) {
+        bool active;
+        V3 o = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+        V3 d = mk(0.f, 0.f, 1.f), T = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
+        uint32_t pix = 0, it_sub = 0;
+        if (p.bounce == 0) {
+            const uint64_t i = ((uint64_t)chunk * kWfSubQueues + q) * kBlockThreads + tid;
+            active = i < n_paths;
+            if (active) {
+                const uint32_t sub = (uint32_t)(i & 3);
+                const uint64_t ip = i >> 2;
+                const uint32_t it_off = (uint32_t)(ip / n_pix);
+                pix = (uint32_t)(ip - (uint64_t)it_off * n_pix);
+                it_sub = ((p.first_iteration + it_off) << 2) | sub;
+                const uint32_t y = pix / p.cam.width, x = pix - y * p.cam.width;
+                d = camera_ray(p.cam, x, y, pix, it_sub >> 2, (int)sub, k0, k1);
+            }
+        } else {
+            const uint32_t slot_in = chunk * kBlockThreads + tid;
+            active = slot_in < n_items;
+            if (active) {
+                const size_t s = (size_t)q * p.sub_capacity + slot_in;
+                const float4 a = p.in.a[s], bb = p.in.b[s], c = p.in.c[s];
+                const uint2 id = p.in.path[s];
+                o = mk(a.x, a.y, a.z); d = mk(a.w, bb.x, bb.y); T = mk(bb.z, bb.w, c.x); L = mk(c.y, c.z, c.w);
+                pix = id.x; it_sub = id.y;
+            }
+        }
+
+        float tmax;
+        int best;
+        intersect_scene<TILED>(p.scene, sc, lds_raw, tid, active, o, d, tmax, best);
+
+        bool cont = false;
+        if (active) {
+            bool end = true;
+            int b = p.bounce;
+            if (best >= 0) {
+                const float4 s = TILED ? p.scene.sph[best] : sc.sph[best];
+                end = shade_bounce(sc, s, best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
+            }
+            if (end) {
+                const size_t path = (((size_t)((it_sub >> 2) - p.first_iteration) * n_pix + pix) << 2) | (it_sub & 3);
+                float *pr = p.path_radiance + path * 3;
+                pr[0] = L.x; pr[1] = L.y; pr[2] = L.z;
+            }
+            cont = !end;
+        }
+
+        // compaction: one atomic per wave reserves the survivors' slots in the same sub-queue
+        const unsigned long long mask = __ballot(cont);
+        if (mask) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const int leader = (int)__builtin_ctzll(mask);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(count_ptr(p.counts, p.bounce + 1, q), (uint32_t)__popcll(mask));
+            base = __shfl(base, leader, 64);
+            if (cont) {
+                const size_t s = (size_t)q * p.sub_capacity + base + rank;
+                p.out.a[s] = make_float4(o.x, o.y, o.z, d.x);
+                p.out.b[s] = make_float4(d.y, d.z, T.x, T.y);
+                p.out.c[s] = make_float4(T.z, L.x, L.y, L.z);
+                p.out.path[s] = make_uint2(pix, it_sub);
+            }
+        }
+    }
+}
+
+// Folds the batch's path radiances into the frame buffer: per pixel, iteration by iteration,
+// c = (((0+L0)+L1)+L2)+L3) * 1/4 and the running mean / sum of RenderKernel (pathtracer.cu:94-109).
+__global__ __launch_bounds__(kBlockThreads) void wf_resolve_kernel(const WavefrontParams p)
+{
+    const uint32_t n_pix = p.cam.width * p.cam.height;
+    const uint32_t pix = blockIdx.x * kBlockThreads + threadIdx.x;
+    if (pix < n_pix) {
+        float *px = p.buffer + (size_t)pix * 3;
+        V3 acc = p.overwrite ? mk(0.f, 0.f, 0.f) : mk(px[0], px[1], px[2]);
+        for (uint32_t k = 0; k < p.n_iterations; ++k) {
+            const float *pr = p.path_radiance + (((size_t)k * n_pix + pix) << 2) * 3;
+            V3 c = mk(0.f, 0.f, 0.f);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) c = c + mk(pr[s * 3], pr[s * 3 + 1], pr[s * 3 + 2]);
+            acc = accumulate_pixel(acc, c, p.first_iteration + k, p.accum_mode);
+        }
+        px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
+    }
+    // Intersect calls of the batch = paths entering each bounce
+    if (blockIdx.x == 0 && threadIdx.x < kWfSubQueues && p.ray_counter) {
+        unsigned long long n = 0;
+        for (int b = 1; b <= p.max_bounces; ++b) n += *count_ptr(p.counts, b, threadIdx.x);
+        if (threadIdx.x == 0) n += (unsigned long long)p.n_iterations * n_pix * 4;
+        atomicAdd(p.ray_counter, n);
+    }
+}
+
+} // namespace
+
+hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream_t stream)
+{
+    // 64 sub-queues x up to 32 workgroups each (2048 workgroups = one resident set of the chip);
+    // a workgroup walks its sub-queue's chunks with stride gridDim.y and returns at once when the
+    // sub-queue is shorter than its first chunk.
+    const uint32_t chunks = p.sub_capacity / kBlockThreads;
+    const dim3 grid(kWfSubQueues, chunks < 32u ? chunks : 32u), block(kBlockThreads);
+    const size_t lds = scene_lds_bytes(p.scene, tiled);
+    if (tiled) hipLaunchKernelGGL(wf_step_kernel<true>, grid, block, lds, stream, p);
+    else       hipLaunchKernelGGL(wf_step_kernel<false>, grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_wavefront_resolve(const WavefrontParams &p, hipStream_t stream)
+{
+    const uint32_t n_pix = p.cam.width * p.cam.height;
+    hipLaunchKernelGGL(wf_resolve_kernel, dim3((n_pix + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace ptmi

@@ -143,8 +143,13 @@ int pt_set_row_bands(pt_handle h, uint32_t band_rows, uint32_t rank, uint32_t wo
  * pt_reset_counters; waits for the stream. */
 int pt_ray_count(pt_handle h, uint64_t *out);
 int pt_reset_counters(pt_handle h);
-/* Kernel variant: 0 = persistent lanes with path regeneration (default), 1 = one lane per
- * pixel-iteration without regeneration.  Results are identical; for profiling. */
+/* Kernel variant; results are bit-identical in all of them.
+ *   PT_VARIANT_REGENERATION (default): megakernel, persistent lanes with path regeneration
+ *   PT_VARIANT_CLASSIC: megakernel, a wave starts new paths only when all its lanes are idle
+ *   2..64: megakernel, regeneration once that many lanes of a wave are idle (experiments)
+ *   PT_VARIANT_WAVEFRONT: one launch per bounce over compacted path queues in device memory
+ *     (allocates about 4 GiB of queues on first use; no row bands) */
+enum { PT_VARIANT_REGENERATION = 0, PT_VARIANT_CLASSIC = 1, PT_VARIANT_WAVEFRONT = 100 };
 int pt_set_kernel_variant(pt_handle h, int variant);
 /* HIP-event time of the last pt_run/pt_run_n launch in milliseconds (waits for it). */
 int pt_last_kernel_ms(pt_handle h, float *ms);

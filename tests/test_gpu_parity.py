@@ -143,15 +143,40 @@ def test_run_per_iteration_equals_batched_and_host_buffer(pt, torch_cuda):
     tr.Release()
 
 
+@pytest.mark.parametrize("name", golden_names())
+def test_wavefront_variant_matches_golden_bit_exact(pt, torch_cuda, name):
+    """The path-compaction (one launch per bounce) variant: same bits, same ray count."""
+    g = load_golden(name)
+    tr = make_tracer(pt, g, pt.VARIANT_WAVEFRONT)
+    tr.ResetCounters()
+    buf = render(torch_cuda, tr, int(g["first_iteration"]), int(g["n_iterations"]))
+    assert tr.RayCount() == int(g["ray_count"])
+    assert buf.cpu().numpy().tobytes() == g["image"].tobytes()
+    # per-iteration launches and SUM mode go through the same batches
+    buf2 = render(torch_cuda, tr, int(g["first_iteration"]), int(g["n_iterations"]), batched=False)
+    assert torch_cuda.equal(buf, buf2)
+    tr.Release()
+
+
+def test_wavefront_rejects_row_bands(pt, torch_cuda):
+    g = load_golden("demo_32x32_d0_it1")
+    tr = make_tracer(pt, g, pt.VARIANT_WAVEFRONT)
+    tr.SetRowBands(16, 0, 2)
+    with pytest.raises(pt.PtError) as e:
+        tr.Run(torch_cuda.zeros(32 * 32 * 3, device="cuda"))
+    assert e.value.code == pt.PT_ERR_STATE
+    tr.Release()
+
+
 def test_kernel_variants_agree(pt, torch_cuda):
     """Path regeneration changes scheduling only: identical bits with and without it."""
     g = load_golden("mixed_64x64_d16_it1-2")
     imgs = []
-    for variant in (0, 1, 16):
+    for variant in (0, 1, 16, pt.VARIANT_WAVEFRONT):
         tr = make_tracer(pt, g, variant)
         imgs.append(render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes())
         tr.Release()
-    assert imgs[0] == imgs[1] == imgs[2] == g["image"].tobytes()
+    assert imgs[0] == imgs[1] == imgs[2] == imgs[3] == g["image"].tobytes()
 
 
 def test_tile_split_is_bit_exact(pt, torch_cuda):
