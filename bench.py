@@ -69,9 +69,23 @@ def cpu_baseline(pt, wl, mats, sph, lights, cam):
     _, _, _, rays = O.oracle_render(cam.pod, mats, sph, lights, 1, wl["depth"], first_iteration=1,
                                     n_iterations=iters, rect=(0, y0, w, y0 + rows), n_threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": rays / dt, "unit": "path-bounces/s", "cores": threads, "kind": "port",
-            "sample": f"{wl['label']}: rows {y0}..{y0 + rows} x {iters} iteration(s), {rays} Intersect calls "
-                      f"in {dt:.2f} s on {threads} threads (oracle/pt_oracle.c)"}
+    out = {"value": rays / dt, "unit": "path-bounces/s", "cores": threads, "kind": "port",
+           "sample": f"{wl['label']}: rows {y0}..{y0 + rows} x {iters} iteration(s), {rays} Intersect calls "
+                     f"in {dt:.2f} s on {threads} threads (oracle/pt_oracle.c)"}
+    if O.have_ref():
+        # the reference's own trace logic compiled for host (oracle/_ref, prebuilt in the
+        # development container), single-threaded as the reference is, on a smaller sample
+        rows1 = max(1, min(h, int(5.0 * rate / rays_per_row)))
+        y1 = (h - rows1) // 2
+        t0 = time.perf_counter()
+        _, _, _, rays1 = O.ref_render(cam.eye, cam.look_at, cam.up, w, h, cam.fov, mats, sph, lights, 1,
+                                      wl["depth"], rect=(0, y1, w, y1 + rows1))
+        dt1 = time.perf_counter() - t0
+        out["reference_host_build"] = {"value": rays1 / dt1, "unit": "path-bounces/s", "cores": 1,
+                                       "kind": "reference",
+                                       "sample": f"rows {y1}..{y1 + rows1} x 1 iteration, {rays1} Intersect "
+                                                 f"calls in {dt1:.2f} s, 1 thread (oracle/_ref/libpt_ref.so)"}
+    return out
 
 
 def main():

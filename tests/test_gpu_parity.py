@@ -293,3 +293,53 @@ def test_full_size_properties_1080p(pt, O, torch_cuda):
                                    rect=(0, 1072, 1920, 1080), n_threads=8)
     assert img[1072:].tobytes() == ref[1072:].tobytes()
     tr.Release()
+
+
+def test_config3_size_4k_tile_split_over_8_ranks(pt, torch_cuda):
+    """BASELINE config 3's frame (3840x2160) split into 16-row bands over 8 ranks: the sum of
+    the ranks' buffers is the 1-rank image bit for bit, and the ray counts add up."""
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
+    cam = pt.Camera(eye, look, up, 3840, 2160, 0, 0, fov)
+    one = pt.Pathtracer(cam, 8, 1)
+    one.Init(mats, sph, lights)
+    one.ResetCounters()
+    full = render(torch_cuda, one, 1, 2)
+    rays_full = one.RayCount()
+    one.Release()
+    total = torch_cuda.zeros_like(full)
+    rays = 0
+    for rank in range(8):
+        tr = pt.Pathtracer(cam, 8, 1)
+        tr.Init(mats, sph, lights)
+        tr.SetRowBands(16, rank, 8)
+        tr.ResetCounters()
+        total += render(torch_cuda, tr, 1, 2)
+        rays += tr.RayCount()
+        tr.Release()
+    assert rays == rays_full
+    assert torch_cuda.equal(total, full)
+
+
+def test_config4_size_synth10k_1080p_rows_against_oracle(pt, O, torch_cuda):
+    """BASELINE config 4 (10 007 spheres, 1080p): one iteration through the LDS-tiled scan;
+    four rows spread over the frame are compared with the oracle bit for bit."""
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_SYNTH10K, 1)
+    cam = pt.Camera(eye, look, up, 1920, 1080, 0, 0, fov)
+    tr = pt.Pathtracer(cam, 8, 1)
+    tr.Init(mats, sph, lights)
+    img = render(torch_cuda, tr, 1, 1).cpu().numpy().reshape(1080, 1920, 3)
+    wf = make_wavefront_image(pt, torch_cuda, cam, mats, sph, lights, 8)
+    assert img.tobytes() == wf.tobytes()
+    for y in (0, 337, 702, 1079):
+        ref, _, _, _ = O.oracle_render(cam.pod, mats, sph, lights, 1, 8, rect=(0, y, 1920, y + 1), n_threads=8)
+        assert img[y].tobytes() == ref[y].tobytes(), y
+    tr.Release()
+
+
+def make_wavefront_image(pt, torch, cam, mats, sph, lights, depth):
+    tr = pt.Pathtracer(cam, depth, 1)
+    tr.Init(mats, sph, lights)
+    tr.SetKernelVariant(pt.VARIANT_WAVEFRONT)
+    img = render(torch, tr, 1, 1).cpu().numpy().reshape(cam.Height(), cam.Width(), 3)
+    tr.Release()
+    return img

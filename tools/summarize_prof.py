@@ -37,17 +37,30 @@ def main():
     # PMC: average per launch of the render kernel
     sums, counts = defaultdict(float), defaultdict(int)
     meta = {}
+    kernels = set()
     for path in sorted(glob.glob(os.path.join(base, "*", "pmc_counter_collection.csv"))):
         with open(path) as f:
             for r in csv.DictReader(f):
-                if "render_kernel" not in r["Kernel_Name"]:
+                if "render_kernel" not in r["Kernel_Name"] and "wf_" not in r["Kernel_Name"]:
                     continue
                 sums[r["Counter_Name"]] += float(r["Counter_Value"])
                 counts[r["Counter_Name"]] += 1
+                if "wf_step" in r["Kernel_Name"] or "render_kernel" in r["Kernel_Name"]:
+                    kernels.add(r["Kernel_Name"])
                 meta = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size",
                                           "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r}
-    avg = {k: sums[k] / counts[k] for k in sums}
-    print("## PMC counters, average per `render_kernel` launch\n")
+    # the megakernel is one launch per bench step; the wavefront variant is many launches per
+    # step, so its counters are summed over all launches of the run and divided by the number of
+    # bench steps (warm-up included) to stay comparable
+    n_steps = 1
+    for line in cmd.splitlines():
+        if line.startswith("{"):
+            import json
+            j = json.loads(line)
+            n_steps = j["steps"] + j["warmup"]
+    wavefront = any("wf_" in k for k in kernels)
+    avg = {k: (sums[k] / n_steps if wavefront else sums[k] / counts[k]) for k in sums}
+    print(f"## PMC counters per bench step ({'sum over all wf_* launches of a step' if wavefront else 'one render_kernel launch'})\n")
     print("launch: " + ", ".join(f"{k}={v}" for k, v in meta.items()) + "\n")
     print("| counter | value |\n|---|---|")
     for k in sorted(avg):
