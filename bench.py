@@ -185,6 +185,13 @@ def main():
     launch_ms = region_ms / args.steps if world == 1 else tr.LastKernelMs()
     rays_per_launch = rays_local / max(1, args.steps)
     fpr = flops_per_ray(len(sph))
+    # HBM bytes per step from the committed PMC passes of this same command (rocprofv3 cannot be
+    # run from inside the benchmark): profiles/pmc_traffic_<workload>_v<variant>.json
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}_v{args.variant}.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("hbm_bytes_per_step")
     achieved = rays_per_launch * fpr / (launch_ms * 1e-3) / 1e12
 
     if rank == 0:
@@ -204,7 +211,7 @@ def main():
                        "parallelism": "single" if world == 1 else f"sample-range split x{world} + RCCL reduce(sum)",
                        "kernel_variant": args.variant},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
                          "kernel": "render_kernel", "launch_ms": launch_ms,
                          "flops_per_bounce": fpr, "bounces_per_launch": rays_per_launch},
         }

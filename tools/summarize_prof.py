@@ -85,6 +85,16 @@ def main():
                 print(f"* {k} / SQ_WAVE_CYCLES: {g(k) / g('SQ_WAVE_CYCLES'):.3f}")
     if g("GRBM_GUI_ACTIVE") and g("SQ_INSTS_VALU"):
         print(f"* VALU wave-instructions per GRBM_GUI_ACTIVE cycle (sum over XCDs): {g('SQ_INSTS_VALU') / g('GRBM_GUI_ACTIVE'):.2f}")
+    if g("FETCH_SIZE") is not None and len(sys.argv) > 2:
+        # machine-readable HBM traffic per bench step for bench.py's roofline.traffic:
+        # FETCH_SIZE is doubled (gfx950 tallies 128-B read requests at 64 B), WRITE_SIZE taken as is;
+        # both are reported in KiB
+        import json
+        with open(sys.argv[2], "w") as f:
+            json.dump({"tag": tag, "fetch_bytes": g("FETCH_SIZE") * 1024 * 2, "write_bytes": g("WRITE_SIZE", 0.0) * 1024,
+                       "hbm_bytes_per_step": g("FETCH_SIZE") * 1024 * 2 + g("WRITE_SIZE", 0.0) * 1024,
+                       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per bench step; "
+                               "FETCH_SIZE x2 (gfx950 correction for wide coalesced reads)"}, f, indent=1)
     if g("FETCH_SIZE") is not None:
         print(f"* FETCH_SIZE {g('FETCH_SIZE'):.6g} KB as reported (x2 on gfx950 for 16 B/lane streaming reads), "
               f"WRITE_SIZE {g('WRITE_SIZE', float('nan')):.6g} KB")
