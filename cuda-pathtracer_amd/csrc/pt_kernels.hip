@@ -22,7 +22,7 @@ namespace ptmi {
 
 namespace {
 
-template <bool TILED, bool RECORD>
+template <bool TILED, bool RECORD, bool RING>
 __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -63,6 +63,19 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
     int b = 0;
     uint32_t nrays = 0;
 
+    // ---- camera-ray ring (small resident scenes) -----------------------------------------------
+    // Generating a camera ray costs two thirds of a bounce of shading, and in every loop pass
+    // only the ~quarter of the lanes whose path just ended need one: done inline, the whole
+    // wave pays for it on every pass.  Instead each lane keeps a ring of 8 rays (two
+    // pixel-iterations) in LDS.  Only when some lane has run dry does the wave enter the
+    // generation block, and then EVERY lane with room generates its next pixel-iteration
+    // (4 rays, 2 Philox blocks): the block runs every ~7 passes with about half the lanes active.
+    // The ring costs 96 B of LDS per lane (6 instead of 8 workgroups per CU), which only pays
+    // while ray generation is a large share of a pass, i.e. for scenes of a few spheres.
+    float *ring = reinterpret_cast<float *>(lds_raw + scene_lds_bytes_dev(p.scene));
+    uint32_t gen = 0;    // pixel-iterations generated into the ring so far
+    uint32_t cons = 0;   // paths started so far; path q is (iteration q/4, sub-sample q%4)
+
     for (;;) {
         // ---- path regeneration ---------------------------------------------------------------
         // regen_min_idle = 1: any idle lane restarts at once; 64: lanes restart only when the
@@ -72,9 +85,30 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
             const int idle = __popcll(__ballot(!alive));
             want = want && idle >= p.regen_min_idle;
         }
+        if (RING) {
+            if (__any(want && cons == gen * 4u)) {
+                if (!done && gen < p.n_iterations && gen * 4u - cons <= 4u) {
+                    V3 dirs[4];
+                    camera_rays4(p.cam, x, y, pix, p.first_iteration + gen, k0, k1, dirs);
+                    const uint32_t base = (gen & 1u) * 4u;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        float *slot = ring + ((base + s) * 3u) * kBlockThreads + tid;
+                        slot[0] = dirs[s].x; slot[kBlockThreads] = dirs[s].y; slot[2 * kBlockThreads] = dirs[s].z;
+                    }
+                    ++gen;
+                }
+            }
+        }
         if (want) {
             o = cam_pos;
-            d = camera_ray(p.cam, x, y, pix, it, sub, k0, k1);
+            if (RING) {
+                const float *slot = ring + ((cons & 7u) * 3u) * kBlockThreads + tid;
+                d = mk(slot[0], slot[kBlockThreads], slot[2 * kBlockThreads]);
+                ++cons;
+            } else {
+                d = camera_ray(p.cam, x, y, pix, it, sub, k0, k1);
+            }
             T = mk(1.f, 1.f, 1.f);
             L = mk(0.f, 0.f, 0.f);
             b = 0;
@@ -201,21 +235,34 @@ hipError_t launch_selftest_exhaustive(int op, unsigned long long *mismatches, hi
 size_t scene_lds_bytes(const SceneParams &s, bool tiled)
 {
     if (tiled) return (size_t)kTileSpheres * sizeof(float4);
-    return (size_t)s.n_prims * 2 * sizeof(float4) + (size_t)s.n_mats * (sizeof(float4) + sizeof(int)) +
-           (size_t)s.n_lights * sizeof(float4);
+    const size_t n = (size_t)s.n_prims * 2 * sizeof(float4) + (size_t)s.n_mats * (sizeof(float4) + sizeof(int)) +
+                     (size_t)s.n_lights * sizeof(float4);
+    return (n + 15) & ~(size_t)15;
+}
+
+// LDS of the megakernel: the scene, plus (resident scenes only) the camera-ray ring,
+// 8 rays x 3 floats per lane.
+static size_t render_lds_bytes(const SceneParams &s, bool tiled, bool ring)
+{
+    return scene_lds_bytes(s, tiled) + (ring ? (size_t)8 * 3 * kBlockThreads * sizeof(float) : 0);
 }
 
 hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled,
                          bool record, hipStream_t stream)
 {
     const dim3 grid(grid_x, grid_y), block(kBlockThreads);
-    const size_t lds = scene_lds_bytes(p.scene, tiled);
+    // the camera-ray ring pays while a pass is dominated by shading and ray generation
+    const bool ring = !tiled && p.scene.n_prims <= kMaxRingSpheres;
+    const size_t lds = render_lds_bytes(p.scene, tiled, ring);
     if (tiled) {
-        if (record) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, lds, stream, p);
-        else        hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, stream, p);
+        if (record) hipLaunchKernelGGL((render_kernel<true, true, false>), grid, block, lds, stream, p);
+        else        hipLaunchKernelGGL((render_kernel<true, false, false>), grid, block, lds, stream, p);
+    } else if (ring) {
+        if (record) hipLaunchKernelGGL((render_kernel<false, true, true>), grid, block, lds, stream, p);
+        else        hipLaunchKernelGGL((render_kernel<false, false, true>), grid, block, lds, stream, p);
     } else {
-        if (record) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, stream, p);
-        else        hipLaunchKernelGGL((render_kernel<false, false>), grid, block, lds, stream, p);
+        if (record) hipLaunchKernelGGL((render_kernel<false, true, false>), grid, block, lds, stream, p);
+        else        hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, lds, stream, p);
     }
     return hipGetLastError();
 }

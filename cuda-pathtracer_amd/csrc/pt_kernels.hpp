@@ -12,6 +12,8 @@ constexpr uint32_t kTileSpheres = 1024;
 // Scenes up to this many spheres are staged in LDS once per workgroup
 // (32 B per sphere -> 16 KiB at the limit).
 constexpr uint32_t kMaxResidentSpheres = 512;
+// Scenes up to this many spheres also keep a per-lane ring of pre-generated camera rays in LDS.
+constexpr uint32_t kMaxRingSpheres = 24;
 
 // What Camera::GenerateRay reads (camera.h:66-72).
 struct CameraParams {

@@ -19,6 +19,13 @@ PT_DEV uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+// Bytes of LDS stage_scene<false>() fills, rounded up to 16 (device-side twin of scene_lds_bytes).
+PT_DEV uint32_t scene_lds_bytes_dev(const SceneParams &s)
+{
+    const uint32_t n = s.n_prims * 32u + s.n_mats * 20u + s.n_lights * 16u;
+    return (n + 15u) & ~15u;
+}
+
 struct SceneView {
     const float4 *sph;   // LDS: all spheres (resident) or the current tile (streaming)
     const float4 *aux;   // (1/radius, materialId bits, lightId bits, radius)
@@ -107,6 +114,28 @@ PT_DEV V3 camera_ray(const CameraParams &cam, uint32_t x, uint32_t y, uint32_t p
     const V3 pxx = mk(cam.pxx[0], cam.pxx[1], cam.pxx[2]);
     const V3 pxy = mk(cam.pxy[0], cam.pxy[1], cam.pxy[2]);
     return normalize((first - pxy * sy) + pxx * sx);
+}
+
+// The four camera rays of one pixel-iteration at once: the same values camera_ray() returns for
+// sub = 0..3 (Philox slot 0 feeds sub-samples 0 and 1, slot 1 feeds 2 and 3), with two Philox
+// blocks instead of four.
+PT_DEV void camera_rays4(const CameraParams &cam, uint32_t x, uint32_t y, uint32_t pix, uint32_t it,
+                         uint32_t k0, uint32_t k1, V3 dirs[4])
+{
+    const V3 first = mk(cam.first[0], cam.first[1], cam.first[2]);
+    const V3 pxx = mk(cam.pxx[0], cam.pxx[1], cam.pxx[2]);
+    const V3 pxy = mk(cam.pxy[0], cam.pxy[1], cam.pxy[2]);
+    const float fx = (float)(int)x, fy = (float)(int)y;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint32_t r[4];
+        philox4x32_10(pix, it, (uint32_t)half, STREAM_CAMERA, k0, k1, r);
+        const float vs = half ? 0.5f : -0.5f;
+        const float sx0 = fx + u01(r[0]) * -0.5f, sy0 = fy + u01(r[1]) * vs;
+        const float sx1 = fx + u01(r[2]) * 0.5f, sy1 = fy + u01(r[3]) * vs;
+        dirs[half * 2] = normalize((first - pxy * sy0) + pxx * sx0);
+        dirs[half * 2 + 1] = normalize((first - pxy * sy1) + pxx * sx1);
+    }
 }
 
 // One iteration of the loop in Trace (pathtracer.cu:125-168) for a ray that hit sphere `best`
