@@ -25,6 +25,7 @@ struct pt_context {
     int accum_mode;
     uint32_t band_rows, band_rank, band_world;
     int regen_min_idle;
+    int small_scene_opts;
     hipStream_t stream;
     int device;
     // scene (device)
@@ -109,6 +110,7 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->accum_mode = PT_ACCUM_RUNNING_MEAN;
     h->band_rows = 0; h->band_rank = 0; h->band_world = 1;
     h->regen_min_idle = 1;
+    h->small_scene_opts = 1;
     h->stream = nullptr;
     h->device = dev;
     h->d_sph = h->d_aux = h->d_mat = h->d_light = nullptr;
@@ -283,7 +285,9 @@ int pt_set_kernel_variant(pt_handle h, int variant)
 {
     if (!h) return PT_ERR_INVALID;
     h->wavefront = false;
+    h->small_scene_opts = 1;
     if (variant == PT_VARIANT_WAVEFRONT) h->wavefront = true;
+    else if (variant >= 300 && variant <= 301) { h->regen_min_idle = 1; h->small_scene_opts = variant - 300; } // experiments
     else if (variant == 0) h->regen_min_idle = 1;
     else if (variant == 1) h->regen_min_idle = 64;
     else if (variant >= 2 && variant <= 64) h->regen_min_idle = variant; // experimental: idle-lane threshold
@@ -326,6 +330,7 @@ static void fill_params(const pt_context *h, RenderParams &p)
     p.seed = h->seed;
     p.max_bounces = h->max_bounces;
     p.regen_min_idle = h->regen_min_idle;
+    p.small_scene_opts = h->small_scene_opts;
 }
 
 static uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }

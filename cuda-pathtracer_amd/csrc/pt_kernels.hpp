@@ -46,6 +46,7 @@ struct RenderParams {
     int accum_mode;           // 0 running mean, 1 sum
     int overwrite;            // 1: start from zero instead of reading the buffer
     int regen_min_idle;       // 1..64, idle lanes needed before a wave starts new paths
+    int small_scene_opts;     // bit 0: camera-ray ring (scenes <= kMaxRingSpheres)
     // outputs
     float *buffer;                     // width*height*3, may be NULL (debug trace)
     unsigned long long *ray_counter;   // += number of Intersect calls

@@ -104,6 +104,14 @@ DEF_KERNEL_F32(k_lshr, "v_lshrrev_b32 %0, 1, %0")
 DEF_KERNEL_F32(k_bfe, "v_bfe_u32 %0, %0, 1, 31")
 DEF_KERNEL_F32(k_or, "v_or_b32 %0, %1, %0")
 DEF_KERNEL_F32(k_readlane, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+DEF_KERNEL_F32(k_mul_lit2, "v_mul_f32 %0, 0x3e2aaaab, %0")
+DEF_KERNEL_F32(k_add_lit2, "v_add_f32 %0, 0x3e2aaaab, %0")
+DEF_KERNEL_F32(k_fmac_v, "v_fmac_f32 %0, %1, %2")
+DEF_KERNEL_F32(k_fmaak, "v_fmaak_f32 %0, %1, %0, 0x3e2aaaab")
+DEF_KERNEL_F32(k_fmamk, "v_fmamk_f32 %0, %1, 0x3e2aaaab, %0")
+DEF_KERNEL_F32(k_xor_s, "v_xor_b32 %0, s10, %0")
+DEF_KERNEL_F32(k_mov_s, "v_mov_b32 %0, s10")
+DEF_KERNEL_F32(k_fma_s2, "v_fma_f32 %0, %1, s10, %0")
 DEF_KERNEL_PK(k_pk_fma, "v_pk_fma_f32 %0, %1, %2, %0")
 DEF_KERNEL_PK(k_pk_mul, "v_pk_mul_f32 %0, %1, %0")
 DEF_KERNEL_PK(k_pk_add, "v_pk_add_f32 %0, %1, %0")
@@ -134,6 +142,9 @@ int main() {
         {"v_add_f32 inline", k_add_inl, 1}, {"v_add_u32", k_addu, 1}, {"v_add_f32 neg", k_sub_neg, 1},
         {"v_add_f32_e64", k_add_e64, 1}, {"v_min_f32", k_min, 1}, {"v_lshrrev_b32", k_lshr, 1},
         {"v_bfe_u32", k_bfe, 1}, {"v_or_b32", k_or, 1}, {"v_mov_dpp", k_readlane, 1},
+        {"v_mul_f32 literal", k_mul_lit2, 1}, {"v_add_f32 literal", k_add_lit2, 1}, {"v_fmac_f32 vgpr", k_fmac_v, 1},
+        {"v_fmaak_f32 lit", k_fmaak, 1}, {"v_fmamk_f32 lit", k_fmamk, 1}, {"v_xor_b32 sgpr", k_xor_s, 1},
+        {"v_mov_b32 sgpr", k_mov_s, 1}, {"v_fma_f32 sgpr", k_fma_s2, 1},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));

@@ -16,7 +16,12 @@ int main(int argc, char **argv)
     const uint32_t iters = argc > 4 ? atoi(argv[4]) : 64;
     const int depth = argc > 5 ? atoi(argv[5]) : 8;
     const int repeats = argc > 6 ? atoi(argv[6]) : 3;
-    const int variant = argc > 7 ? atoi(argv[7]) : 0;
+    // comma-separated list of kernel variants, run interleaved in this one process
+    std::vector<int> variants;
+    {
+        const char *v = argc > 7 ? argv[7] : "0";
+        for (const char *q = v; *q;) { variants.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; }
+    }
 
     uint32_t nm = 0, ns = 0, nl = 0;
     float eye[3], look[3], up[3], fov;
@@ -28,12 +33,13 @@ int main(int argc, char **argv)
     pt_handle hd;
     if (pt_create(&hd, &cam, depth, 1) != PT_OK) { printf("%s\n", pt_last_error(nullptr)); return 1; }
     if (pt_init_scene(hd, m.data(), nm, s.data(), ns, l.data(), nl) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
-    pt_set_kernel_variant(hd, variant);
     float *buf;
     const size_t n = (size_t)w * h * 3;
     if (hipMalloc((void **)&buf, n * sizeof(float)) != hipSuccess) return 1;
     std::vector<float> img(n);
-    for (int r = 0; r < repeats; ++r) {
+    for (int r = 0; r < repeats * (int)variants.size(); ++r) {
+        const int variant = variants[r % variants.size()];
+        if (pt_set_kernel_variant(hd, variant) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
         pt_reset(hd); pt_reset_counters(hd);
         const auto t0 = std::chrono::steady_clock::now();
         if (pt_run_n(hd, buf, iters, 1) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
