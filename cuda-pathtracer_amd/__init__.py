@@ -26,6 +26,9 @@ SPHERE_DTYPE = np.dtype([("pos", "<f4", 3), ("radius", "<f4"), ("material_id", "
                          ("light_id", "<i4")])
 # light.h:47-52: the union {Point pos; uint32 primId} is exposed as raw words
 LIGHT_DTYPE = np.dtype([("type", "<i4"), ("u_bits", "<u4", 3), ("intensity", "<f4", 3)])
+CAMERA_STATE_DTYPE = np.dtype([("view", "<f4", (3, 3)), ("dist", "<f4"), ("hfov", "<f4"), ("vfov", "<f4"),
+                               ("pod", CAMERA_DTYPE)])
+assert CAMERA_STATE_DTYPE.itemsize == 104
 assert CAMERA_DTYPE.itemsize == 56 and MATERIAL_DTYPE.itemsize == 20
 assert SPHERE_DTYPE.itemsize == 24 and LIGHT_DTYPE.itemsize == 28
 
@@ -62,6 +65,9 @@ ABI = [
     ("pt_debug_trace", _i32, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _pu64]),
     ("pt_selftest_eval", _i32, [_vp, _i32, _vp, _vp, _vp, _u64]),
     ("pt_selftest_exhaustive", _i32, [_vp, _i32, _pu64]),
+    ("pt_camera_state_init", _i32, [_vp, _vp, _vp, _vp, _u32, _u32, ctypes.c_float]),
+    ("pt_camera_translate", _i32, [_vp, _vp]),
+    ("pt_camera_rotate", _i32, [_vp, _vp]),
     ("pt_camera_init", _i32, [_vp, _vp, _vp, _vp, _u32, _u32, ctypes.c_float]),
     ("pt_scene_build", _i32, [_i32, _u64, _vp, _pu32, _vp, _pu32, _vp, _pu32, _vp, _vp, _vp, _pf]),
     ("pt_version", _i32, []),
@@ -113,17 +119,38 @@ class Camera:
                  focal_distance: float = 0.0, fov: float = 60.0):
         self.eye, self.look_at, self.up = _f3(eye), _f3(look_at), _f3(up)
         self.fov = float(fov)
-        self.pod = np.zeros(1, dtype=CAMERA_DTYPE)
-        rc = load_library().pt_camera_init(_ptr(self.pod), _ptr(self.eye), _ptr(self.look_at),
-                                           _ptr(self.up), width, height, self.fov)
+        self._state = np.zeros(1, dtype=CAMERA_STATE_DTYPE)
+        rc = load_library().pt_camera_state_init(_ptr(self._state), _ptr(self.eye), _ptr(self.look_at),
+                                                 _ptr(self.up), width, height, self.fov)
         if rc != PT_OK:
-            raise PtError(rc, "pt_camera_init: invalid arguments")
+            raise PtError(rc, "pt_camera_state_init: invalid arguments")
+        self._updated = True
+
+    @property
+    def pod(self) -> np.ndarray:
+        """The derived camera vectors GenerateRay reads (what pt_create / pt_set_camera take)."""
+        return self._state["pod"]
 
     def Width(self) -> int:
         return int(self.pod["width"][0])
 
     def Height(self) -> int:
         return int(self.pod["height"][0])
+
+    def Translate(self, delta) -> None:
+        """camera.h:79-90: move by delta along the camera's own u, v, w axes."""
+        load_library().pt_camera_translate(_ptr(self._state), _ptr(_f3(delta)))
+        self._updated = True
+
+    def Rotate(self, theta) -> None:
+        """camera.h:97-129."""
+        load_library().pt_camera_rotate(_ptr(self._state), _ptr(_f3(theta)))
+        self._updated = True
+
+    def IsUpdated(self) -> bool:
+        """camera.h:134: reports and clears the changed flag."""
+        b, self._updated = self._updated, False
+        return b
 
 
 def build_scene(scene_id: int = SCENE_DEMO, seed: int = 1):

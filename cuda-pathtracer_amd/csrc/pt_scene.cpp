@@ -155,9 +155,102 @@ void build_mixed(SceneData &s)
         }
 }
 
+// Camera::UpdateParameter, camera.h:144-158; Radians, globals.h:95-97
+void update_parameter(pt_camera_state *c)
+{
+    const H3 u = h3(c->view[0][0], c->view[0][1], c->view[0][2]);
+    const H3 v = h3(c->view[1][0], c->view[1][1], c->view[1][2]);
+    const H3 w = h3(c->view[2][0], c->view[2][1], c->view[2][2]);
+    const float m_pi = 3.14159265358979323846f;
+    const uint32_t width = c->pod.width, height = c->pod.height;
+    float magnitude = c->dist * 2.f * tanf((m_pi / 180.f) * (c->hfov * 0.5f)) / (float)width;
+    const H3 pxX = u * magnitude;
+    magnitude = c->dist * 2.f * tanf((m_pi / 180.f) * (c->vfov * 0.5f)) / (float)height;
+    const H3 pxY = v * magnitude;
+    const H3 offset = pxY * (float)((float)height * 0.5f) - pxX * (float)((float)width * 0.5f);
+    const H3 first = w * c->dist + offset;
+    c->pod.px_x[0] = pxX.x; c->pod.px_x[1] = pxX.y; c->pod.px_x[2] = pxX.z;
+    c->pod.px_y[0] = pxY.x; c->pod.px_y[1] = pxY.y; c->pod.px_y[2] = pxY.z;
+    c->pod.first_ray_dir[0] = first.x; c->pod.first_ray_dir[1] = first.y; c->pod.first_ray_dir[2] = first.z;
+}
+
+// Matrix::operator*, geometry.h:249-258, on 4x4 matrices whose last row/column are (0,0,0,1)
+void mat_mul(const float a[4][4], const float b[4][4], float r[4][4])
+{
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            r[i][j] = a[i][0] * b[0][j] + a[i][1] * b[1][j] + a[i][2] * b[2][j] + a[i][3] * b[3][j];
+}
+
 } // namespace
 
 extern "C" {
+
+int pt_camera_state_init(pt_camera_state *cam, const float eye[3], const float look_at[3],
+                         const float up_[3], uint32_t width, uint32_t height, float fov)
+{
+    if (!cam || !eye || !look_at || !up_ || width == 0 || height == 0) return PT_ERR_INVALID;
+    // Camera::Camera, camera.h:31-57
+    const float aspect = (float)height / (float)width;
+    cam->hfov = fov;
+    cam->vfov = cam->hfov * aspect;
+    const H3 e = h3(eye[0], eye[1], eye[2]), up = h3(up_[0], up_[1], up_[2]);
+    const H3 lookAt = h3(look_at[0], look_at[1], look_at[2]) - e;
+    cam->dist = hlength(lookAt);
+    const H3 w = hdiv(lookAt, cam->dist);
+    const H3 v = hnormalize(up - w * hdot(up, w));
+    const H3 u = hnormalize(hcross(w, v));
+    cam->view[0][0] = u.x; cam->view[0][1] = u.y; cam->view[0][2] = u.z;
+    cam->view[1][0] = v.x; cam->view[1][1] = v.y; cam->view[1][2] = v.z;
+    cam->view[2][0] = w.x; cam->view[2][1] = w.y; cam->view[2][2] = w.z;
+    cam->pod.pos[0] = e.x; cam->pod.pos[1] = e.y; cam->pod.pos[2] = e.z;
+    cam->pod.width = width; cam->pod.height = height;
+    update_parameter(cam);
+    return PT_OK;
+}
+
+int pt_camera_translate(pt_camera_state *cam, const float delta[3])
+{
+    if (!cam || !delta) return PT_ERR_INVALID;
+    // camera.h:79-90: pos += u*delta.x + v*delta.y + w*delta.z; the image plane does not change
+    const H3 u = h3(cam->view[0][0], cam->view[0][1], cam->view[0][2]);
+    const H3 v = h3(cam->view[1][0], cam->view[1][1], cam->view[1][2]);
+    const H3 w = h3(cam->view[2][0], cam->view[2][1], cam->view[2][2]);
+    const H3 step = (u * delta[0] + v * delta[1]) + w * delta[2];
+    cam->pod.pos[0] += step.x; cam->pod.pos[1] += step.y; cam->pod.pos[2] += step.z;
+    return PT_OK;
+}
+
+int pt_camera_rotate(pt_camera_state *cam, const float theta[3])
+{
+    if (!cam || !theta) return PT_ERR_INVALID;
+    // camera.h:97-129 -- note the reference's naming: the "x-axis" matrix uses theta.y and the
+    // "y-axis" matrix theta.x; theta.z is ignored
+    const float ctx = theta[0] == 0.f ? 1.f : cosf(theta[0]);
+    const float cty = theta[1] == 0.f ? 1.f : cosf(theta[1]);
+    const float stx = theta[0] == 0.f ? 0.f : sinf(theta[0]);
+    const float sty = theta[1] == 0.f ? 0.f : sinf(theta[1]);
+    const float rx[4][4] = { {1.f, 0.f, 0.f, 0.f}, {0.f, cty, -sty, 0.f}, {0.f, sty, cty, 0.f}, {0.f, 0.f, 0.f, 1.f} };
+    const float ry[4][4] = { {ctx, 0.f, stx, 0.f}, {0.f, 1.f, 0.f, 0.f}, {-stx, 0.f, ctx, 0.f}, {0.f, 0.f, 0.f, 1.f} };
+    float view[4][4] = { {cam->view[0][0], cam->view[0][1], cam->view[0][2], 0.f},
+                         {cam->view[1][0], cam->view[1][1], cam->view[1][2], 0.f},
+                         {cam->view[2][0], cam->view[2][1], cam->view[2][2], 0.f},
+                         {0.f, 0.f, 0.f, 1.f} };
+    float out[4][4];
+    if (theta[0] == 0.f) {
+        mat_mul(rx, view, out);
+    } else if (theta[1] == 0.f) {
+        mat_mul(ry, view, out);
+    } else {
+        float rxy[4][4];
+        mat_mul(rx, ry, rxy);
+        mat_mul(rxy, view, out);
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) cam->view[i][j] = out[i][j];
+    update_parameter(cam);
+    return PT_OK;
+}
 
 int pt_camera_init(pt_camera_pod *out, const float eye[3], const float look_at[3],
                    const float up_[3], uint32_t width, uint32_t height, float fov)

@@ -43,23 +43,37 @@ struct Color {
 // evaluates the constructor's and UpdateParameter()'s expressions in the reference's order.
 class Camera {
 public:
-    Camera() : pod_{} {}
+    Camera() : state_{} {}
     Camera(const Point &eye, const Point &lookAtP, const Vec &up, uint32_t iw, uint32_t ih,
            float /*lensRadius*/, float /*focalDistance*/, float fov)
     {
         const float e[3] = {eye.x, eye.y, eye.z}, l[3] = {lookAtP.x, lookAtP.y, lookAtP.z}, u[3] = {up.x, up.y, up.z};
-        if (pt_camera_init(&pod_, e, l, u, iw, ih, fov) != PT_OK) throw std::invalid_argument("Camera: bad arguments");
+        if (pt_camera_state_init(&state_, e, l, u, iw, ih, fov) != PT_OK) throw std::invalid_argument("Camera: bad arguments");
         updated_ = true;
     }
-    uint32_t Width() const { return pod_.width; }
-    uint32_t Height() const { return pod_.height; }
-    Point GetPos() const { return Point(pod_.pos[0], pod_.pos[1], pod_.pos[2]); }
+    // camera.h:79-90
+    void Translate(const Vec &delta)
+    {
+        const float d[3] = {delta.x, delta.y, delta.z};
+        pt_camera_translate(&state_, d);
+        updated_ = true;
+    }
+    // camera.h:97-129
+    void Rotate(const Vec &theta)
+    {
+        const float t[3] = {theta.x, theta.y, theta.z};
+        pt_camera_rotate(&state_, t);
+        updated_ = true;
+    }
+    uint32_t Width() const { return state_.pod.width; }
+    uint32_t Height() const { return state_.pod.height; }
+    Point GetPos() const { return Point(state_.pod.pos[0], state_.pod.pos[1], state_.pod.pos[2]); }
     // camera.h:134
     bool IsUpdated() { const bool b = updated_; updated_ = false; return b; }
-    const pt_camera_pod &Pod() const { return pod_; }
+    const pt_camera_pod &Pod() const { return state_.pod; }
 
 private:
-    pt_camera_pod pod_;
+    pt_camera_state state_;
     bool updated_ = false;
 };
 

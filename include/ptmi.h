@@ -185,6 +185,22 @@ int pt_selftest_exhaustive(pt_handle h, int op, uint64_t *mismatches);
 int pt_camera_init(pt_camera_pod *out, const float eye[3], const float look_at[3],
                    const float up[3], uint32_t width, uint32_t height, float fov_deg);
 
+/* Interactive camera (camera.h:79-129,144-158): the full state Translate/Rotate work on.  `pod` is
+ * kept up to date and is what pt_create / pt_set_camera take. */
+typedef struct {
+    float view[3][3];   /* rows u, v, w of the view matrix (camera.h:49-54) */
+    float dist, hfov, vfov;
+    pt_camera_pod pod;
+} pt_camera_state;
+
+/* Camera::Camera, camera.h:31-57 (same result in `pod` as pt_camera_init). */
+int pt_camera_state_init(pt_camera_state *cam, const float eye[3], const float look_at[3],
+                         const float up[3], uint32_t width, uint32_t height, float fov_deg);
+/* Camera::Translate, camera.h:79-90: pos += u*dx + v*dy + w*dz. */
+int pt_camera_translate(pt_camera_state *cam, const float delta[3]);
+/* Camera::Rotate, camera.h:97-129 (theta.z is ignored as in the reference), then UpdateParameter. */
+int pt_camera_rotate(pt_camera_state *cam, const float theta[3]);
+
 typedef enum {
     PT_SCENE_DEMO = 0,      /* InitScene "scene 2", main.cpp:129-164: 9 spheres, 1 area light */
     PT_SCENE_SYNTH10K = 1,  /* demo room + 10 000 procedural spheres */

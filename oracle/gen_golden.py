@@ -110,7 +110,15 @@ def main():
                         fov=np.float32(fov), sizes=np.array(sizes, np.uint32), pods=pods,
                         eye2=eye2, look_at2=look2, up2=up2, fov2=np.float32(75.0), pod2=pod2,
                         sizeof=np.array([ref.ref_sizeof(i) for i in range(11)], np.int32))
-    print("cameras.npz written")
+    # interactive camera: a keyboard/mouse session's worth of Translate / Rotate calls
+    # (main.cpp:249-364 uses steps of 1.0 and 0.05 rad) through the reference's own methods
+    ops = np.array([(0, 1, 0, 0), (0, 0, 0, -1), (1, 0.05, 0, 0), (1, 0, -0.05, 0), (0, -2.5, 0.5, 3),
+                    (1, 0.3, 0.2, 0), (1, -0.7, 0.1, 0.4), (0, 0, 1, 0), (1, 0, 0.05, 0), (1, 0.05, 0, 0)],
+                   np.float32)
+    pods_moved = O.ref_camera_moves(eye, look, up, 640, 480, fov, ops)
+    np.savez_compressed(os.path.join(GOLDEN, "camera_moves.npz"), eye=eye, look_at=look, up=up,
+                        fov=np.float32(fov), width=640, height=480, ops=ops, pods=pods_moved)
+    print("cameras.npz, camera_moves.npz written")
 
 
 if __name__ == "__main__":

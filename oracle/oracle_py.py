@@ -138,3 +138,40 @@ def ref_render(eye, look_at, up, width, height, fov, mats, prims, lights, seed, 
     if rc != 0:
         raise ValueError("ref_render: invalid arguments")
     return buffer, hits, rad, int(cnt.value)
+
+
+# ---- interactive camera (camera.h:79-129) ---------------------------------------------------------
+CAMERA_STATE_DTYPE = np.dtype([("view", "<f4", (3, 3)), ("dist", "<f4"), ("hfov", "<f4"), ("vfov", "<f4"),
+                               ("cam", CAMERA_DTYPE)])
+
+
+def camera_moves(eye, look_at, up, width, height, fov, ops):
+    """Oracle: camera PODs before and after each move; ops = [(kind, x, y, z)], kind 0 Translate,
+    1 Rotate.  Returns an array of len(ops) + 1 CAMERA_DTYPE records."""
+    lib = load_oracle()
+    for name in ("ptor_camera_state_init", "ptor_camera_translate", "ptor_camera_rotate"):
+        getattr(lib, name).restype = None
+    lib.ptor_camera_state_init.argtypes = [_vp, _vp, _vp, _vp, _u32, _u32, ctypes.c_float]
+    lib.ptor_camera_translate.argtypes = [_vp, _vp]
+    lib.ptor_camera_rotate.argtypes = [_vp, _vp]
+    st = np.zeros(1, CAMERA_STATE_DTYPE)
+    e, l, u = (np.ascontiguousarray(v, np.float32) for v in (eye, look_at, up))
+    lib.ptor_camera_state_init(_ptr(st), _ptr(e), _ptr(l), _ptr(u), width, height, fov)
+    pods = [st["cam"].copy()]
+    for kind, x, y, z in ops:
+        v = np.array([x, y, z], np.float32)
+        (lib.ptor_camera_rotate if kind else lib.ptor_camera_translate)(_ptr(st), _ptr(v))
+        pods.append(st["cam"].copy())
+    return np.concatenate(pods)
+
+
+def ref_camera_moves(eye, look_at, up, width, height, fov, ops):
+    """The reference's own Camera::Translate / Rotate (libm build of the harness)."""
+    lib = load_ref(libm=True)
+    lib.ref_camera_moves.restype = None
+    lib.ref_camera_moves.argtypes = [_vp, _vp, _vp, _u32, _u32, ctypes.c_float, _vp, _u32, _vp]
+    e, l, u = (np.ascontiguousarray(v, np.float32) for v in (eye, look_at, up))
+    o = np.ascontiguousarray(ops, np.float32).reshape(-1, 4)
+    pods = np.zeros(len(o) + 1, CAMERA_DTYPE)
+    lib.ref_camera_moves(_ptr(e), _ptr(l), _ptr(u), width, height, fov, _ptr(o), len(o), _ptr(pods))
+    return pods

@@ -288,6 +288,82 @@ void ptor_camera_init(ptor_camera *out, const float eye[3], const float look_at[
     out->width = width; out->height = height;
 }
 
+/* Camera::UpdateParameter, camera.h:144-158 */
+static void camera_update_parameter(ptor_camera_state *st)
+{
+    const v3 u = v3_load(st->view[0]), v = v3_load(st->view[1]), w = v3_load(st->view[2]);
+    const uint32_t width = st->cam.width, height = st->cam.height;
+    float magnitude = st->dist * 2.f * tanf((PT_M_PI / 180.f) * (st->hfov * 0.5f)) / (float)width;
+    const v3 pxX = v3_scale(u, magnitude);
+    magnitude = st->dist * 2.f * tanf((PT_M_PI / 180.f) * (st->vfov * 0.5f)) / (float)height;
+    const v3 pxY = v3_scale(v, magnitude);
+    const v3 offset = v3_sub(v3_scale(pxY, (float)((float)height * 0.5f)),
+                             v3_scale(pxX, (float)((float)width * 0.5f)));
+    const v3 first = v3_add(v3_scale(w, st->dist), offset);
+    st->cam.px_x[0] = pxX.x; st->cam.px_x[1] = pxX.y; st->cam.px_x[2] = pxX.z;
+    st->cam.px_y[0] = pxY.x; st->cam.px_y[1] = pxY.y; st->cam.px_y[2] = pxY.z;
+    st->cam.first_ray_dir[0] = first.x; st->cam.first_ray_dir[1] = first.y; st->cam.first_ray_dir[2] = first.z;
+}
+
+void ptor_camera_state_init(ptor_camera_state *st, const float eye[3], const float look_at[3],
+                            const float up_[3], uint32_t width, uint32_t height, float fov)
+{
+    /* camera.h:31-57 */
+    const float aspect = (float)height / (float)width;
+    st->hfov = fov;
+    st->vfov = st->hfov * aspect;
+    const v3 e = v3_load(eye), up = v3_load(up_);
+    const v3 lookAt = v3_sub(v3_load(look_at), e);
+    st->dist = v3_length(lookAt);
+    const v3 w = v3_div(lookAt, st->dist);
+    const v3 v = v3_normalize(v3_sub(up, v3_scale(w, v3_dot(up, w))));
+    const v3 u = v3_normalize(v3_cross(w, v));
+    st->view[0][0] = u.x; st->view[0][1] = u.y; st->view[0][2] = u.z;
+    st->view[1][0] = v.x; st->view[1][1] = v.y; st->view[1][2] = v.z;
+    st->view[2][0] = w.x; st->view[2][1] = w.y; st->view[2][2] = w.z;
+    st->cam.pos[0] = e.x; st->cam.pos[1] = e.y; st->cam.pos[2] = e.z;
+    st->cam.width = width; st->cam.height = height;
+    camera_update_parameter(st);
+}
+
+/* Camera::Translate, camera.h:79-90 */
+void ptor_camera_translate(ptor_camera_state *st, const float delta[3])
+{
+    const v3 u = v3_load(st->view[0]), v = v3_load(st->view[1]), w = v3_load(st->view[2]);
+    const v3 step = v3_add(v3_add(v3_scale(u, delta[0]), v3_scale(v, delta[1])), v3_scale(w, delta[2]));
+    st->cam.pos[0] += step.x; st->cam.pos[1] += step.y; st->cam.pos[2] += step.z;
+}
+
+/* Matrix::operator*, geometry.h:249-258 */
+static void mat4_mul(const float a[4][4], const float b[4][4], float r[4][4])
+{
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            r[i][j] = a[i][0] * b[0][j] + a[i][1] * b[1][j] + a[i][2] * b[2][j] + a[i][3] * b[3][j];
+}
+
+/* Camera::Rotate, camera.h:97-129 */
+void ptor_camera_rotate(ptor_camera_state *st, const float theta[3])
+{
+    const float ctx = theta[0] == 0.f ? 1.f : cosf(theta[0]);
+    const float cty = theta[1] == 0.f ? 1.f : cosf(theta[1]);
+    const float stx = theta[0] == 0.f ? 0.f : sinf(theta[0]);
+    const float sty = theta[1] == 0.f ? 0.f : sinf(theta[1]);
+    const float rx[4][4] = { {1.f, 0.f, 0.f, 0.f}, {0.f, cty, -sty, 0.f}, {0.f, sty, cty, 0.f}, {0.f, 0.f, 0.f, 1.f} };
+    const float ry[4][4] = { {ctx, 0.f, stx, 0.f}, {0.f, 1.f, 0.f, 0.f}, {-stx, 0.f, ctx, 0.f}, {0.f, 0.f, 0.f, 1.f} };
+    float view[4][4], out[4][4], rxy[4][4];
+    memset(view, 0, sizeof view);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) view[i][j] = st->view[i][j];
+    view[3][3] = 1.f;
+    if (theta[0] == 0.f) mat4_mul(rx, view, out);
+    else if (theta[1] == 0.f) mat4_mul(ry, view, out);
+    else { mat4_mul(rx, ry, rxy); mat4_mul(rxy, view, out); }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) st->view[i][j] = out[i][j];
+    camera_update_parameter(st);
+}
+
 void ptor_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
     ptor_philox4x32_10(ctr, key, out);

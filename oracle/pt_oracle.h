@@ -62,6 +62,17 @@ enum { PTOR_HIT_MISS = -1, PTOR_HIT_NOT_TRACED = -2 };
 void ptor_camera_init(ptor_camera *out, const float eye[3], const float look_at[3],
                       const float up[3], uint32_t width, uint32_t height, float fov_deg);
 
+/* Interactive camera state and its two mutators (camera.h:79-129); `cam` is kept up to date. */
+typedef struct {
+    float view[3][3];
+    float dist, hfov, vfov;
+    ptor_camera cam;
+} ptor_camera_state;
+void ptor_camera_state_init(ptor_camera_state *st, const float eye[3], const float look_at[3],
+                            const float up[3], uint32_t width, uint32_t height, float fov_deg);
+void ptor_camera_translate(ptor_camera_state *st, const float delta[3]);
+void ptor_camera_rotate(ptor_camera_state *st, const float theta[3]);
+
 /* Philox4x32-10 block and the float map, exported for the known-answer tests. */
 void ptor_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void ptor_uniforms(uint64_t seed, uint32_t pixel, uint32_t iteration, uint32_t slot,

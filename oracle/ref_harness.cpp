@@ -115,6 +115,30 @@ void ref_camera_init(ptor_camera *out, const float eye[3], const float look_at[3
     out->width = cam.Width(); out->height = cam.Height();
 }
 
+/* Applies n_ops moves to the reference's Camera: ops[i] = {kind (0 Translate, 1 Rotate), x, y, z};
+ * pods[i] receives the derived vectors after move i (pods[0] is the state before any move, so
+ * pods has n_ops + 1 entries). */
+void ref_camera_moves(const float eye[3], const float look_at[3], const float up[3], uint32_t width,
+                      uint32_t height, float fov, const float *ops, uint32_t n_ops, ptor_camera *pods)
+{
+    Camera cam(Point(eye[0], eye[1], eye[2]), Point(look_at[0], look_at[1], look_at[2]),
+               Vec(up[0], up[1], up[2]), width, height, 0.f, 0.f, fov);
+    for (uint32_t i = 0; i <= n_ops; ++i) {
+        if (i > 0) {
+            const float *op = ops + (size_t)(i - 1) * 4;
+            if (op[0] == 0.f) cam.Translate(Vec(op[1], op[2], op[3]));
+            else cam.Rotate(Vec(op[1], op[2], op[3]));
+        }
+        ptor_camera *out = &pods[i];
+        out->pos[0] = cam.pos.x; out->pos[1] = cam.pos.y; out->pos[2] = cam.pos.z;
+        out->px_x[0] = cam.pxX.x; out->px_x[1] = cam.pxX.y; out->px_x[2] = cam.pxX.z;
+        out->px_y[0] = cam.pxY.x; out->px_y[1] = cam.pxY.y; out->px_y[2] = cam.pxY.z;
+        out->first_ray_dir[0] = cam.firstRayDir.x; out->first_ray_dir[1] = cam.firstRayDir.y;
+        out->first_ray_dir[2] = cam.firstRayDir.z;
+        out->width = cam.Width(); out->height = cam.Height();
+    }
+}
+
 /* Same contract as ptor_render(), but the camera is built by the reference's constructor. */
 int ref_render(const float eye[3], const float look_at[3], const float up[3],
                uint32_t width, uint32_t height, float fov,
