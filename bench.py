@@ -49,8 +49,10 @@ def flops_per_ray(n_spheres: int) -> int:
     return 17 * n_spheres + 121
 
 
-def cpu_baseline(pt, wl, mats, sph, lights, cam):
-    """Time the CPU oracle on a bounded sample of the same workload (about 10-30 s of CPU work)."""
+def cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render=None):
+    """Time the CPU oracle on a bounded sample of the same workload (about 10-30 s of CPU work).
+    gpu_render(n_iterations) -> numpy image: when given, the oracle's rows are also compared with
+    the GPU's image of the same iterations (image RMSE / max abs difference; expected 0)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     threads = max(1, min(16, len(os.sched_getaffinity(0))))
@@ -66,12 +68,18 @@ def cpu_baseline(pt, wl, mats, sph, lights, cam):
         iters, rows = 1, min(h, max(threads, int(budget_rays / rays_per_row)))
     y0 = (h - rows) // 2
     t0 = time.perf_counter()
-    _, _, _, rays = O.oracle_render(cam.pod, mats, sph, lights, 1, wl["depth"], first_iteration=1,
-                                    n_iterations=iters, rect=(0, y0, w, y0 + rows), n_threads=threads)
+    cpu_img, _, _, rays = O.oracle_render(cam.pod, mats, sph, lights, 1, wl["depth"], first_iteration=1,
+                                          n_iterations=iters, rect=(0, y0, w, y0 + rows), n_threads=threads)
     dt = time.perf_counter() - t0
     out = {"value": rays / dt, "unit": "path-bounces/s", "cores": threads, "kind": "port",
            "sample": f"{wl['label']}: rows {y0}..{y0 + rows} x {iters} iteration(s), {rays} Intersect calls "
                      f"in {dt:.2f} s on {threads} threads (oracle/pt_oracle.c)"}
+    if gpu_render is not None:
+        import numpy as np
+        diff = gpu_render(iters)[y0:y0 + rows].astype(np.float64) - cpu_img[y0:y0 + rows]
+        out["image_vs_gpu"] = {"rmse": float(np.sqrt((diff ** 2).mean())), "max_abs": float(np.abs(diff).max()),
+                               "pixels": int(rows * w), "iterations": int(iters),
+                               "note": "GPU image vs this CPU image, same seed and iterations; parity is bit-exact"}
     if O.have_ref():
         # the reference's own trace logic compiled for host (oracle/_ref, prebuilt in the
         # development container), single-threaded as the reference is, on a smaller sample
@@ -216,7 +224,11 @@ def main():
                          "flops_per_bounce": fpr, "bounces_per_launch": rays_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pt, wl, mats, sph, lights, cam)
+            def gpu_render(n):
+                tr.Reset()
+                tr.RunN(buf, n, sync=True)
+                return buf.cpu().numpy().reshape(wl["height"], wl["width"], 3)
+            out["cpu_baseline"] = cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render)
         print(json.dumps(out), flush=True)
 
     tr.Release()
