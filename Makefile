@@ -15,8 +15,9 @@ CSRC     := $(PKG)/csrc
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
             -fhip-fp32-correctly-rounded-divide-sqrt -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
-SRCS := $(CSRC)/pt_kernels.hip $(CSRC)/pt_wavefront.hip $(CSRC)/pt_api.cpp $(CSRC)/pt_scene.cpp
-HDRS := include/ptmi.h $(CSRC)/pt_kernels.hpp $(CSRC)/pt_device.hpp $(CSRC)/pt_trace.hpp
+SRCS := $(CSRC)/pt_kernels.hip $(CSRC)/pt_wavefront.hip $(CSRC)/pt_api.cpp $(CSRC)/pt_scene.cpp \
+        $(CSRC)/pt_bvh.cpp
+HDRS := include/ptmi.h $(CSRC)/pt_kernels.hpp $(CSRC)/pt_device.hpp $(CSRC)/pt_trace.hpp $(CSRC)/pt_bvh.hpp
 
 all: lib oracle
 
@@ -24,6 +25,12 @@ lib: $(PKG)/libptmi.so
 
 $(PKG)/libptmi.so: $(SRCS) $(HDRS) Makefile
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
+
+# Same library with the BVH traversal counters compiled in (pt_accel_stats); measurement only.
+stats: tools/stats/libptmi.so
+tools/stats/libptmi.so: $(SRCS) $(HDRS) Makefile
+	mkdir -p tools/stats
+	$(HIPCC) $(HIPFLAGS) -DPT_BVH_STATS -shared -o $@ $(SRCS)
 
 oracle:
 	$(MAKE) -C oracle all
@@ -42,4 +49,4 @@ clean:
 	rm -f $(PKG)/libptmi.so examples/pt_headless
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle examples clean
+.PHONY: all lib stats oracle examples clean

@@ -11,7 +11,9 @@ There is no fallback: if ``libptmi.so`` has not been built, importing this modul
 from __future__ import annotations
 
 import ctypes
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -38,6 +40,7 @@ ACCUM_RUNNING_MEAN, ACCUM_SUM = 0, 1
 HIT_MISS, HIT_NOT_TRACED = -1, -2
 SCENE_DEMO, SCENE_SYNTH10K, SCENE_MIXED = 0, 1, 2
 VARIANT_REGENERATION, VARIANT_CLASSIC, VARIANT_WAVEFRONT = 0, 1, 100
+ACCEL_AUTO, ACCEL_BRUTE_FORCE = 0, 1
 PT_OK, PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_DEVICE, PT_ERR_NOMEM = 0, -1, -2, -3, -4
 
 # Every symbol include/ptmi.h declares: (name, restype, argtypes)
@@ -60,6 +63,9 @@ ABI = [
     ("pt_ray_count", _i32, [_vp, _pu64]),
     ("pt_reset_counters", _i32, [_vp]),
     ("pt_set_kernel_variant", _i32, [_vp, _i32]),
+    ("pt_set_accel", _i32, [_vp, _i32]),
+    ("pt_accel_nodes", _u32, [_vp]),
+    ("pt_accel_stats", _i32, [_vp, _pu64]),
     ("pt_last_kernel_ms", _i32, [_vp, _pf]),
     ("pt_read_image", _i32, [_vp, _vp, _vp]),
     ("pt_debug_trace", _i32, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _pu64]),
@@ -76,6 +82,30 @@ ABI = [
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.
+
+    A PyTorch-ROCm wheel ships its own libamdhip64 / libhsa-runtime64 and loads them by path.
+    If libptmi.so were loaded first it would bind to the system copies under /opt/rocm, and a
+    later ``import torch`` would bring a second runtime into the process: device pointers of one
+    are foreign to the other, and whichever initialises second may find no device.  Mapping
+    torch's copies first (same SONAME) makes libptmi.so resolve to them in either import order.
+    Without PyTorch installed the system runtime is used as linked."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def load_library() -> ctypes.CDLL:
     """Load libptmi.so (built in-tree by ``make lib``); raises if it is missing."""
     global _lib
@@ -83,6 +113,7 @@ def load_library() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not built: run `make lib` (hipcc --offload-arch=gfx950); "
                               "there is no CPU fallback")
+        _share_hip_runtime_with_torch()
         lib = ctypes.CDLL(LIB_PATH)
         for name, restype, argtypes in ABI:
             fn = getattr(lib, name)
@@ -244,6 +275,19 @@ class Pathtracer:
 
     def SetKernelVariant(self, variant: int) -> None:
         self._check(self._lib.pt_set_kernel_variant(self._h, variant))
+
+    def SetAccel(self, mode: int) -> None:
+        """ACCEL_AUTO: sphere BVH for scenes above 512 spheres; ACCEL_BRUTE_FORCE: linear scan."""
+        self._check(self._lib.pt_set_accel(self._h, mode))
+
+    def AccelNodes(self) -> int:
+        return int(self._lib.pt_accel_nodes(self._h))
+
+    def AccelStats(self):
+        """(inner nodes, leaves, rays, rays visiting everything) -- zeros unless built with PT_BVH_STATS."""
+        out = (_u64 * 4)()
+        self._check(self._lib.pt_accel_stats(self._h, out))
+        return tuple(int(v) for v in out)
 
     def RayCount(self) -> int:
         v = _u64(0)

@@ -6,6 +6,7 @@
 // gfx950 device and reports PT_ERR_DEVICE otherwise.
 #include "ptmi.h"
 #include "pt_kernels.hpp"
+#include "pt_bvh.hpp"
 
 #include <cstdarg>
 #include <cstdio>
@@ -33,6 +34,10 @@ struct pt_context {
     int *d_mat_type;
     uint32_t n_prims, n_mats, n_lights;
     bool scene_ready;
+    // sphere BVH of scenes too large for LDS residency (device); n_nodes == 0: none
+    BvhParams bvh;
+    void *d_bvh;          // one allocation behind the pointers in `bvh`
+    int accel;            // PT_ACCEL_*
     // misc device state
     unsigned long long *d_ray_counter;
     float *d_internal_buffer; // frame buffer owned by the library when the caller passes host memory
@@ -117,6 +122,9 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->d_mat_type = nullptr;
     h->n_prims = h->n_mats = h->n_lights = 0;
     h->scene_ready = false;
+    memset(&h->bvh, 0, sizeof h->bvh);
+    h->d_bvh = nullptr;
+    h->accel = PT_ACCEL_AUTO;
     h->d_ray_counter = nullptr;
     h->d_internal_buffer = nullptr;
     h->ev_start = h->ev_stop = nullptr;
@@ -147,7 +155,52 @@ static void free_scene(pt_context *h)
     if (h->d_mat_type) (void)hipFree(h->d_mat_type);
     h->d_sph = h->d_aux = h->d_mat = h->d_light = nullptr;
     h->d_mat_type = nullptr;
+    if (h->d_bvh) (void)hipFree(h->d_bvh);
+    h->d_bvh = nullptr;
+    memset(&h->bvh, 0, sizeof h->bvh);
     h->scene_ready = false;
+}
+
+// Build the sphere BVH on the host and upload it as one allocation.
+static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sphere *spheres, uint32_t n)
+{
+    std::vector<float> radius(n);
+    for (uint32_t i = 0; i < n; ++i) radius[i] = spheres[i].radius;
+    BvhData d;
+    if (!build_bvh(sph.data(), radius.data(), n, &d)) return PT_OK;   // brute force stays
+    auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    const size_t n_nodes = d.nodes.size() / 4, n_slots = d.leaf_sph.size(), n_big = d.big_sph.size();
+    const size_t off_nodes = 0;
+    const size_t off_ls = off_nodes + pad(d.nodes.size() * sizeof(float4));
+    const size_t off_li = off_ls + pad(n_slots * sizeof(float4));
+    const size_t off_bs = off_li + pad(n_slots * sizeof(int));
+    const size_t off_bi = off_bs + pad((n_big ? n_big : 1) * sizeof(float4));
+    const size_t off_st = off_bi + pad((n_big ? n_big : 1) * sizeof(int));
+    const size_t total = off_st + 256;
+    std::vector<unsigned char> blob(total, 0);
+    memcpy(&blob[off_nodes], d.nodes.data(), d.nodes.size() * sizeof(float4));
+    memcpy(&blob[off_ls], d.leaf_sph.data(), n_slots * sizeof(float4));
+    memcpy(&blob[off_li], d.leaf_index.data(), n_slots * sizeof(int));
+    if (n_big) {
+        memcpy(&blob[off_bs], d.big_sph.data(), n_big * sizeof(float4));
+        memcpy(&blob[off_bi], d.big_index.data(), n_big * sizeof(int));
+    }
+    PT_HIP(h, hipMalloc(&h->d_bvh, total));
+    PT_HIP(h, hipMemcpy(h->d_bvh, blob.data(), total, hipMemcpyHostToDevice));
+    const unsigned char *base = (const unsigned char *)h->d_bvh;
+    h->bvh.nodes = (const float4 *)(base + off_nodes);
+    h->bvh.leaf_sph = (const float4 *)(base + off_ls);
+    h->bvh.leaf_index = (const int4 *)(base + off_li);
+    h->bvh.big_sph = (const float4 *)(base + off_bs);
+    h->bvh.big_index = (const int *)(base + off_bi);
+    h->bvh.stats = (unsigned long long *)((unsigned char *)h->d_bvh + off_st);
+    h->bvh.n_nodes = (uint32_t)n_nodes;
+    h->bvh.n_big = (uint32_t)n_big;
+    h->bvh.depth = d.depth;
+    for (int a = 0; a < 3; ++a) h->bvh.centre[a] = d.centre[a];
+    h->bvh.half_diag = d.half_diag;
+    h->bvh.r_min = d.r_min;
+    return PT_OK;
 }
 
 static void free_wavefront(pt_context *h)
@@ -231,6 +284,10 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
     PT_HIP(h, hipMemcpy(h->d_light, light.data(), light.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(h, hipMemcpy(h->d_mat_type, mtype.data(), mtype.size() * sizeof(int), hipMemcpyHostToDevice));
     h->n_prims = n_spheres; h->n_mats = n_materials; h->n_lights = n_lights;
+    if (n_spheres > kMaxResidentSpheres) {
+        const int rc = upload_bvh(h, sph, spheres, n_spheres);
+        if (rc != PT_OK) { free_scene(h); return rc; }
+    }
     h->scene_ready = true;
     return PT_OK;
 }
@@ -281,6 +338,28 @@ int pt_set_row_bands(pt_handle h, uint32_t band_rows, uint32_t rank, uint32_t wo
     return PT_OK;
 }
 
+int pt_set_accel(pt_handle h, int mode)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (mode != PT_ACCEL_AUTO && mode != PT_ACCEL_BRUTE_FORCE)
+        return fail(h, PT_ERR_INVALID, "pt_set_accel: unknown mode %d", mode);
+    h->accel = mode;
+    return PT_OK;
+}
+
+uint32_t pt_accel_nodes(pt_handle h) { return h ? h->bvh.n_nodes : 0; }
+
+int pt_accel_stats(pt_handle h, uint64_t out[4])
+{
+    if (!h || !out) return PT_ERR_INVALID;
+    memset(out, 0, 4 * sizeof(uint64_t));
+    if (!h->d_bvh) return PT_OK;
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    PT_HIP(h, hipMemcpy(out, h->bvh.stats, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    PT_HIP(h, hipMemset(h->bvh.stats, 0, 4 * sizeof(uint64_t)));
+    return PT_OK;
+}
+
 int pt_set_kernel_variant(pt_handle h, int variant)
 {
     if (!h) return PT_ERR_INVALID;
@@ -320,6 +399,8 @@ static void fill_scene(const pt_context *h, SceneParams &s)
 {
     s.sph = h->d_sph; s.aux = h->d_aux; s.mat = h->d_mat; s.mat_type = h->d_mat_type; s.light = h->d_light;
     s.n_prims = h->n_prims; s.n_mats = h->n_mats; s.n_lights = h->n_lights;
+    if (h->accel == PT_ACCEL_AUTO) s.bvh = h->bvh;
+    else memset(&s.bvh, 0, sizeof s.bvh);
 }
 
 static void fill_params(const pt_context *h, RenderParams &p)

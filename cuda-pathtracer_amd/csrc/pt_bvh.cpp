@@ -1,0 +1,162 @@
+// Host-side build of the sphere BVH used by the accelerated nearest-hit search.
+//
+// The reference only has a brute-force scan ("TODO kd-tree", scene.h:33).  The hierarchy must
+// return exactly what that scan returns -- the lexicographic minimum of (t, index) over the
+// spheres whose fp32 test (primitive.h:39-45) yields a valid t -- so it may only skip spheres
+// that provably cannot produce a valid t below the current bound.  The fp32 test can report hits
+// off the geometric sphere: with op = centre - origin and a direction of squared length 1 + eps
+// (mirror directions are not re-normalised, globals.h:107-109), the point origin + t * dir of a
+// reported t lies at squared distance r^2 + eps * t^2 + err from the centre, where err, the
+// rounding error of det = b*b - op.op + r*r, stays below 1e-6 * |op|^2 * |dir|^2.  Both terms depend on
+// the ray, so the traversal widens every box by a per-ray margin derived from them (pt_trace.hpp,
+// intersect_bvh); the boxes built here bound the exact spheres plus a small fixed slack.
+// Spheres too large to bound usefully (the demo room's radius-1e5 walls, the light) are kept in
+// a separate always-tested list.
+#include "pt_bvh.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace ptmi {
+
+namespace {
+
+struct Item {
+    float c[3];
+    float R;     // radius plus slack
+    int index;   // original sphere index
+};
+
+struct Subtree {
+    int ref;          // >= 0 inner node, < 0 ~leaf
+    float lo[3], hi[3];
+    uint32_t depth;   // inner levels below and including this one
+};
+
+struct Builder {
+    std::vector<Item> items;
+    const float4 *sph;
+    BvhData *out;
+
+    // Recursive median split on the widest axis of the centroid bounds.
+    Subtree build(size_t lo, size_t hi)
+    {
+        Subtree me;
+        float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int a = 0; a < 3; ++a) { me.lo[a] = INFINITY; me.hi[a] = -INFINITY; }
+        for (size_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) {
+                me.lo[a] = std::min(me.lo[a], items[i].c[a] - items[i].R);
+                me.hi[a] = std::max(me.hi[a], items[i].c[a] + items[i].R);
+                cmin[a] = std::min(cmin[a], items[i].c[a]);
+                cmax[a] = std::max(cmax[a], items[i].c[a]);
+            }
+        if (hi - lo <= kBvhLeafSize) {
+            const int leaf = (int)(out->leaf_index.size() / kBvhLeafSize);
+            for (size_t k = 0; k < kBvhLeafSize; ++k) {
+                if (lo + k < hi) {
+                    out->leaf_sph.push_back(sph[items[lo + k].index]);
+                    out->leaf_index.push_back(items[lo + k].index);
+                } else {
+                    // r*r = -inf: det is -inf or NaN for every ray, the test can never succeed
+                    out->leaf_sph.push_back(make_float4(0.f, 0.f, 0.f, -INFINITY));
+                    out->leaf_index.push_back(0x7fffffff);
+                }
+            }
+            me.ref = ~leaf;
+            me.depth = 0;
+            return me;
+        }
+        const int node = (int)(out->nodes.size() / 4);
+        out->nodes.resize(out->nodes.size() + 4);
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+        const size_t mid = (lo + hi) / 2;
+        std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
+                         [axis](const Item &x, const Item &y) {
+                             return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.index < y.index);
+                         });
+        const Subtree c0 = build(lo, mid);
+        const Subtree c1 = build(mid, hi);
+        float r0, r1;
+        memcpy(&r0, &c0.ref, 4);
+        memcpy(&r1, &c1.ref, 4);
+        float4 *n = &out->nodes[(size_t)node * 4];
+        n[0] = make_float4(c0.lo[0], c0.lo[1], c0.lo[2], c0.hi[0]);
+        n[1] = make_float4(c0.hi[1], c0.hi[2], c1.lo[0], c1.lo[1]);
+        n[2] = make_float4(c1.lo[2], c1.hi[0], c1.hi[1], c1.hi[2]);
+        n[3] = make_float4(r0, r1, 0.f, 0.f);
+        me.ref = node;
+        me.depth = 1 + std::max(c0.depth, c1.depth);
+        return me;
+    }
+};
+
+} // namespace
+
+bool build_bvh(const float4 *sph, const float *radius, uint32_t n, BvhData *out)
+{
+    out->nodes.clear(); out->leaf_sph.clear(); out->leaf_index.clear();
+    out->big_sph.clear(); out->big_index.clear();
+    out->depth = 0;
+    if (n == 0) return false;
+
+    // spheres much larger than the typical one cannot be bounded usefully: always-tested list
+    // (the sphere test only sees r*r, so a negative radius acts like its magnitude)
+    std::vector<float> rad(n);
+    for (uint32_t i = 0; i < n; ++i) rad[i] = std::fabs(radius[i]);
+    radius = rad.data();
+    std::vector<float> radii(rad);
+    std::nth_element(radii.begin(), radii.begin() + (n * 3) / 4, radii.end());
+    const float big_threshold = 8.f * radii[(n * 3) / 4];
+    std::vector<uint32_t> small;
+    for (uint32_t i = 0; i < n; ++i) {
+        const bool finite = std::isfinite(radius[i]) && std::isfinite(sph[i].x) && std::isfinite(sph[i].y) &&
+                            std::isfinite(sph[i].z);
+        if (!finite || !(radius[i] <= big_threshold)) {
+            out->big_sph.push_back(sph[i]);
+            out->big_index.push_back((int)i);
+        } else {
+            small.push_back(i);
+        }
+    }
+    if (small.size() <= kBvhLeafSize || out->big_sph.size() > kBvhMaxBig) return false;
+
+    // cloud of the bounded spheres: centre and half-diagonal
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i : small) {
+        const float c[3] = {sph[i].x, sph[i].y, sph[i].z};
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], c[a] - radius[i]);
+            hi[a] = std::max(hi[a], c[a] + radius[i]);
+        }
+    }
+    double hd2 = 0;
+    for (int a = 0; a < 3; ++a) {
+        out->centre[a] = 0.5f * (lo[a] + hi[a]);
+        hd2 += 0.25 * (double)(hi[a] - lo[a]) * (double)(hi[a] - lo[a]);
+    }
+    out->half_diag = (float)(std::sqrt(hd2) * (1.0 + 1e-6));
+    out->r_min = INFINITY;
+    const double slack = 1e-6 * std::sqrt(hd2) + 1e-4;
+
+    Builder b;
+    b.sph = sph;
+    b.out = out;
+    b.items.reserve(small.size());
+    for (uint32_t i : small) {
+        Item it;
+        it.c[0] = sph[i].x; it.c[1] = sph[i].y; it.c[2] = sph[i].z;
+        it.R = (float)(((double)radius[i] + slack) * (1.0 + 1e-6));
+        it.index = (int)i;
+        b.items.push_back(it);
+        out->r_min = std::min(out->r_min, radius[i]);
+    }
+    const Subtree root = b.build(0, b.items.size());   // more than one leaf: the root is inner node 0
+    out->depth = root.depth;
+    return root.depth <= kBvhMaxDepth;
+}
+
+} // namespace ptmi

@@ -22,7 +22,7 @@ namespace ptmi {
 
 namespace {
 
-template <bool TILED, bool RECORD, bool RING>
+template <bool TILED, bool RECORD, bool RING, bool BVH>
 __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
             b = 0;
             alive = true;
         }
-        if (TILED) {
+        if (TILED && !BVH) {
             if (!__syncthreads_or(alive)) break;
         } else {
             if (!__any(alive)) break;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
 
         float tmax;
         int best;
-        intersect_scene<TILED>(p.scene, sc, lds_raw, tid, alive, o, d, tmax, best);
+        intersect_scene<TILED, BVH>(p.scene, sc, lds_raw, tid, alive, o, d, tmax, best);
 
         if (alive) {
             ++nrays;
@@ -254,14 +254,17 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y
     // Small resident scenes keep a camera-ray ring (p.small_scene_opts bit 0; experiments can
     // switch it off).  A branch-free variant of the scan was measured 3.5 % slower and dropped.
     const bool ring = !tiled && p.scene.n_prims <= kMaxRingSpheres && (p.small_scene_opts & 1);
-    const size_t lds = render_lds_bytes(p.scene, tiled, ring);
-#define PT_LAUNCH(T, R, G) hipLaunchKernelGGL((render_kernel<T, R, G>), grid, block, lds, stream, p)
-    if (tiled) {
-        if (record) PT_LAUNCH(true, true, false); else PT_LAUNCH(true, false, false);
+    const bool bvh = tiled && p.scene.bvh.n_nodes > 0;
+    const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : render_lds_bytes(p.scene, tiled, ring);
+#define PT_LAUNCH(T, R, G, B) hipLaunchKernelGGL((render_kernel<T, R, G, B>), grid, block, lds, stream, p)
+    if (bvh) {
+        if (record) PT_LAUNCH(true, true, false, true); else PT_LAUNCH(true, false, false, true);
+    } else if (tiled) {
+        if (record) PT_LAUNCH(true, true, false, false); else PT_LAUNCH(true, false, false, false);
     } else if (ring) {
-        if (record) PT_LAUNCH(false, true, true); else PT_LAUNCH(false, false, true);
+        if (record) PT_LAUNCH(false, true, true, false); else PT_LAUNCH(false, false, true, false);
     } else {
-        if (record) PT_LAUNCH(false, true, false); else PT_LAUNCH(false, false, false);
+        if (record) PT_LAUNCH(false, true, false, false); else PT_LAUNCH(false, false, false, false);
     }
 #undef PT_LAUNCH
     return hipGetLastError();

@@ -21,8 +21,23 @@ struct CameraParams {
     uint32_t width, height;
 };
 
+// Sphere BVH in device memory (layout: pt_bvh.hpp); n_nodes == 0 when there is none.
+struct BvhParams {
+    const float4 *nodes;      // four float4 per inner node, node 0 is the root
+    const float4 *leaf_sph;   // [leaf][4]
+    const int4 *leaf_index;   // [leaf]
+    const float4 *big_sph;
+    const int *big_index;
+    uint32_t n_nodes, n_big;
+    uint32_t depth;           // entries of the per-lane traversal stack
+    float centre[3];
+    float half_diag, r_min;
+    unsigned long long *stats;   // 4 counters, written only by -DPT_BVH_STATS builds
+};
+
 // Scene, SoA in device memory.
 struct SceneParams {
+    BvhParams bvh;
     const float4 *sph;   // (cx, cy, cz, radius*radius)
     const float4 *aux;   // (1/radius, materialId bits, lightId bits, radius)
     const float4 *mat;   // (r, g, b, coef)
@@ -56,6 +71,8 @@ struct RenderParams {
 };
 
 size_t scene_lds_bytes(const SceneParams &s, bool tiled);
+// LDS of the BVH kernels: the per-lane traversal stacks, [depth][256] entries of 8 bytes.
+inline size_t bvh_stack_lds_bytes(const BvhParams &b) { return (size_t)(b.depth ? b.depth : 1) * 256 * 8; }
 
 // grid_x x grid_y workgroups of 256 threads, each a 16x16 pixel tile.
 hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled,

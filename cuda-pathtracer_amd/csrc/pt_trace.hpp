@@ -77,15 +77,168 @@ PT_DEV void scan_lds(const float4 *sph, int base, int count, V3 o, V3 d, float &
     for (; i < count; ++i) sphere_test(sph[i], base + i, o, d, tmax, best);
 }
 
-// Intersect (scene.h:71-94).  With TILED every thread of the workgroup must call it (barriers);
-// `active` masks the lanes that actually carry a ray.
-template <bool TILED>
+// The sphere test with the order-independent acceptance rule of the BVH search: the brute-force
+// scan keeps the lowest index among equal distances because it visits spheres in index order;
+// visiting them in any order, (t, index) must be compared lexicographically to get the same.
+PT_DEV void sphere_test_lex(float4 s, int index, V3 o, V3 d, float &tmax, int &best)
+{
+    const float opx = s.x - o.x, opy = s.y - o.y, opz = s.z - o.z;
+    const float b = opx * d.x + opy * d.y + opz * d.z;
+    const float det = b * b - (opx * opx + opy * opy + opz * opz) + s.w;
+    if (!(det < 0.f)) {
+        const float sq = pt_sqrt(det);
+        float t = b - sq;
+        if (!(t > PT_EPSILON)) t = b + sq;
+        if (t > PT_EPSILON && (t < tmax || (t == tmax && best >= 0 && index < best))) { tmax = t; best = index; }
+    }
+}
+
+// Slab test of one child box, widened by `e` on every side, against the ray.  NaN-conservative:
+// fminf / fmaxf drop a NaN operand (0 * inf when the origin lies on a slab plane of an axis the
+// ray does not move along), and the negated comparisons enter a box whose interval is NaN
+// altogether.
+PT_DEV bool slab_test(float lx, float ly, float lz, float hx, float hy, float hz, V3 o, float e, V3 inv,
+                      float tmax, float &tnear, float &tfar)
+{
+    const float t1x = ((lx - e) - o.x) * inv.x, t2x = ((hx + e) - o.x) * inv.x;
+    const float t1y = ((ly - e) - o.y) * inv.y, t2y = ((hy + e) - o.y) * inv.y;
+    const float t1z = ((lz - e) - o.z) * inv.z, t2z = ((hz + e) - o.z) * inv.z;
+    tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
+                            __builtin_fminf(t1z, t2z));
+    tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
+                           __builtin_fmaxf(t1z, t2z));
+    return !(tnear > tfar) && !(tfar < 0.f) && !(tnear > tmax);
+}
+
+// Per-ray constants of the box widening, see intersect_bvh.
+struct BvhMargin {
+    float eps;     // max(|dir|^2 - 1, 0) + rounding allowance
+    float err;     // 1e-6 * L^2 * |dir|^2: rounding error of the sphere test's discriminant
+    float slack;   // rounding of the slab arithmetic
+    float r_min;
+    PT_DEV float at(float T) const
+    {
+        const float E2 = eps * T * T + err;
+        return E2 / (__builtin_sqrtf(r_min * r_min + E2) + r_min) * 1.001f + slack;
+    }
+};
+
+// One child box: widened for hits anywhere up to T0 first; rays whose direction is noticeably
+// longer than 1 then narrow the widening to what hits inside this box can need (their t cannot
+// exceed the exit distance of the widely widened box) and test again.
+PT_DEV bool bvh_box_test(float lx, float ly, float lz, float hx, float hy, float hz, V3 o, V3 inv, float e0,
+                         bool refine, const BvhMargin &m, float tmax, float &tnear)
+{
+    float tfar;
+    bool hit = slab_test(lx, ly, lz, hx, hy, hz, o, e0, inv, tmax, tnear, tfar);
+    if (hit && refine) {
+        const float e1 = m.at(__builtin_fminf(tfar * 1.00001f, tmax));
+        if (e1 < e0) hit = slab_test(lx, ly, lz, hx, hy, hz, o, e1, inv, tmax, tnear, tfar);
+    }
+    return hit;
+}
+
+// Nearest hit through the sphere BVH (host side: pt_bvh.cpp).  Depth-first, nearer child first,
+// the farther one deferred on a per-lane stack in LDS (`stack`, [B.depth][kBlockThreads]) together
+// with its entry distance, so that it is dropped when a closer hit has been found meanwhile.
+// A box is entered when the ray's slab interval through the widened box overlaps [0, tmax].
+// The widening is per ray: a valid t of the fp32 sphere test puts origin + t * dir at squared
+// distance r^2 + (|dir|^2 - 1) * t^2 + err from the centre, err < 1e-6 * |op|^2 * |dir|^2, op =
+// centre - origin (derivation in pt_bvh.cpp).  With eps >= |dir|^2 - 1, T >= t and L >= |op| for every
+// bounded sphere, e(T) = sqrt(r_min^2 + eps * T^2 + err(L)) - r_min covers all of them (the
+// excess shrinks as r grows); the slab arithmetic's own rounding is added on top.  Mirror
+// directions are not re-normalised (globals.h:107-109) and can be several per cent too long
+// after a bounce off a small sphere, so eps is not always tiny.  t itself is below tmax and
+// below (2 |dir| + 0.1) L: the hit lies about r from a centre, and |op| + r <= L.
+// A skipped box therefore cannot hold a sphere whose test would succeed with t <= tmax, and
+// sphere_test_lex makes the visiting order irrelevant: the result equals the brute-force scan's.
+PT_DEV void intersect_bvh(const BvhParams &B, uint2 *stack, int tid, V3 o, V3 d, float &tmax, int &best)
+{
+    for (uint32_t i = 0; i < B.n_big; ++i) sphere_test_lex(B.big_sph[i], B.big_index[i], o, d, tmax, best);
+    const float cx = o.x - B.centre[0], cy = o.y - B.centre[1], cz = o.z - B.centre[2];
+    const float L = __builtin_sqrtf(cx * cx + cy * cy + cz * cz) * 1.000001f + B.half_diag;
+    const float excess = (d.x * d.x + d.y * d.y + d.z * d.z) - 1.f;
+    // a NaN in the origin or the direction makes every sphere test fail (all comparisons false)
+    if (excess != excess || L != L) return;
+    BvhMargin m;
+    m.eps = __builtin_fmaxf(excess, 0.f) * 1.000001f + 4e-7f;
+    // b = op . dir grows with |dir|, and with it the rounding errors of b * b and of t = b -+ sqrt(det)
+    m.err = 1e-6f * L * L * (1.f + m.eps);
+    m.slack = 2e-6f * L * (1.f + m.eps);
+    m.r_min = B.r_min;
+    float e = m.at(__builtin_fminf(tmax, (2.2f * (1.f + m.eps) + 0.1f) * L));
+    bool refine = m.eps > 2e-6f;
+    // overflow (absurdly long directions, far origins): visit everything, like the scan
+    if (!(e < 3.0e38f)) { e = PT_INF; refine = false; }
+    const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    stack += tid;
+    int cur = 0, sp = 0;
+#ifdef PT_BVH_STATS
+    uint32_t st_nodes = 0, st_leaves = 0;
+#define PT_BVH_COUNT(x) (++(x))
+#else
+#define PT_BVH_COUNT(x) ((void)0)
+#endif
+    for (;;) {
+        if (cur >= 0) {
+            PT_BVH_COUNT(st_nodes);
+            const float4 *N = B.nodes + 4 * (size_t)cur;
+            const float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+            float tn0, tn1;
+            const bool hit0 = bvh_box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, inv, e, refine, m, tmax, tn0);
+            const bool hit1 = bvh_box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, inv, e, refine, m, tmax, tn1);
+            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            if (hit0 && hit1) {
+                const bool first0 = tn0 <= tn1;
+                stack[sp * kBlockThreads] = make_uint2((uint32_t)(first0 ? c1 : c0), __float_as_uint(first0 ? tn1 : tn0));
+                ++sp;
+                cur = first0 ? c0 : c1;
+                continue;
+            }
+            if (hit0 || hit1) {
+                cur = hit0 ? c0 : c1;
+                continue;
+            }
+        } else {
+            PT_BVH_COUNT(st_leaves);
+            const uint32_t leaf = (uint32_t)~cur;
+            const float4 *S = B.leaf_sph + 4 * (size_t)leaf;
+            const float4 s0 = S[0], s1 = S[1], s2 = S[2], s3 = S[3];
+            const int4 id = B.leaf_index[leaf];
+            sphere_test_lex(s0, id.x, o, d, tmax, best);
+            sphere_test_lex(s1, id.y, o, d, tmax, best);
+            sphere_test_lex(s2, id.z, o, d, tmax, best);
+            sphere_test_lex(s3, id.w, o, d, tmax, best);
+        }
+        // next deferred box that can still hold a hit at or below tmax
+        for (;;) {
+            if (sp == 0) {
+#ifdef PT_BVH_STATS
+                atomicAdd(B.stats + 0, (unsigned long long)st_nodes);
+                atomicAdd(B.stats + 1, (unsigned long long)st_leaves);
+                atomicAdd(B.stats + 2, 1ull);
+                if (!(e < PT_INF)) atomicAdd(B.stats + 3, 1ull);
+#endif
+                return;
+            }
+            --sp;
+            const uint2 top = stack[sp * kBlockThreads];
+            if (!(__uint_as_float(top.y) > tmax)) { cur = (int)top.x; break; }
+        }
+    }
+}
+
+// Intersect (scene.h:71-94).  With TILED (and not BVH) every thread of the workgroup must call
+// it (barriers); `active` masks the lanes that actually carry a ray.
+template <bool TILED, bool BVH = false>
 PT_DEV void intersect_scene(const SceneParams &p, const SceneView &sc, unsigned char *lds_raw, int tid,
                             bool active, V3 o, V3 d, float &tmax, int &best)
 {
     tmax = PT_INF;
     best = -1;
-    if (TILED) {
+    if (BVH) {
+        if (active) intersect_bvh(p.bvh, reinterpret_cast<uint2 *>(lds_raw), tid, o, d, tmax, best);
+    } else if (TILED) {
         float4 *lds_sph = reinterpret_cast<float4 *>(lds_raw);
         for (uint32_t base = 0; base < p.n_prims; base += kTileSpheres) {
             const uint32_t count = min(kTileSpheres, p.n_prims - base);

@@ -24,7 +24,7 @@ PT_DEV uint32_t *count_ptr(uint32_t *counts, int bounce, uint32_t q)
     return counts + ((size_t)bounce * kWfSubQueues + q) * kWfCountStride;
 }
 
-template <bool TILED>
+template <bool TILED, bool BVH>
 __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
 
         float tmax;
         int best;
-        intersect_scene<TILED>(p.scene, sc, lds_raw, tid, active, o, d, tmax, best);
+        intersect_scene<TILED, BVH>(p.scene, sc, lds_raw, tid, active, o, d, tmax, best);
 
         bool cont = false;
         if (active) {
@@ -155,9 +155,11 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
     // sub-queue is shorter than its first chunk.
     const uint32_t chunks = p.sub_capacity / kBlockThreads;
     const dim3 grid(kWfSubQueues, chunks < 32u ? chunks : 32u), block(kBlockThreads);
-    const size_t lds = scene_lds_bytes(p.scene, tiled);
-    if (tiled) hipLaunchKernelGGL(wf_step_kernel<true>, grid, block, lds, stream, p);
-    else       hipLaunchKernelGGL(wf_step_kernel<false>, grid, block, lds, stream, p);
+    const bool bvh = tiled && p.scene.bvh.n_nodes > 0;
+    const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : scene_lds_bytes(p.scene, tiled);
+    if (bvh)        hipLaunchKernelGGL((wf_step_kernel<true, true>), grid, block, lds, stream, p);
+    else if (tiled) hipLaunchKernelGGL((wf_step_kernel<true, false>), grid, block, lds, stream, p);
+    else            hipLaunchKernelGGL((wf_step_kernel<false, false>), grid, block, lds, stream, p);
     return hipGetLastError();
 }
 

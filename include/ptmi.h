@@ -151,6 +151,19 @@ int pt_reset_counters(pt_handle h);
  *     (allocates about 4 GiB of queues on first use; no row bands) */
 enum { PT_VARIANT_REGENERATION = 0, PT_VARIANT_CLASSIC = 1, PT_VARIANT_WAVEFRONT = 100 };
 int pt_set_kernel_variant(pt_handle h, int variant);
+/* Nearest-hit search of scenes with more than 512 spheres; results are bit-identical.
+ *   PT_ACCEL_AUTO (default): sphere BVH built by pt_init_scene -- the acceleration structure
+ *     the reference leaves as "TODO kd-tree" (scene.h:33) -- when the scene allows one
+ *   PT_ACCEL_BRUTE_FORCE: the reference's linear scan over all spheres (scene.h:71-94),
+ *     streamed through LDS in tiles
+ * pt_accel_nodes returns the number of BVH nodes the scene got (0: none, the scan is used). */
+enum { PT_ACCEL_AUTO = 0, PT_ACCEL_BRUTE_FORCE = 1 };
+int pt_set_accel(pt_handle h, int mode);
+uint32_t pt_accel_nodes(pt_handle h);
+/* Traversal counters since the last call: inner nodes visited, leaves visited, rays traversed,
+ * rays that had to visit everything.  Only libraries built with -DPT_BVH_STATS count (the
+ * counting costs time); others return zeros. */
+int pt_accel_stats(pt_handle h, uint64_t out[4]);
 /* HIP-event time of the last pt_run/pt_run_n launch in milliseconds (waits for it). */
 int pt_last_kernel_ms(pt_handle h, float *ms);
 

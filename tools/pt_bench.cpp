@@ -1,7 +1,9 @@
 // Quick A/B harness over the C ABI (no Python start-up): renders a built-in workload a few
 // times and prints time, bounces/s and an FNV-1a hash of the frame buffer, so that a kernel
 // change can be checked for speed and for bit-identical output in one short GPU call.
-//   pt_bench <scene 0|1|2> <width> <height> <iterations> <depth> <repeats> [variant] [lds_pad]
+//   pt_bench <scene 0|1|2> <width> <height> <iterations> <depth> <repeats> [variants]
+// variants: comma-separated pt_set_kernel_variant values; +1000 selects the brute-force scan
+// (PT_ACCEL_BRUTE_FORCE) for that entry.
 #include "ptmi.h"
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -33,13 +35,15 @@ int main(int argc, char **argv)
     pt_handle hd;
     if (pt_create(&hd, &cam, depth, 1) != PT_OK) { printf("%s\n", pt_last_error(nullptr)); return 1; }
     if (pt_init_scene(hd, m.data(), nm, s.data(), ns, l.data(), nl) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
+    printf("spheres %u, bvh nodes %u\n", ns, pt_accel_nodes(hd));
     float *buf;
     const size_t n = (size_t)w * h * 3;
     if (hipMalloc((void **)&buf, n * sizeof(float)) != hipSuccess) return 1;
     std::vector<float> img(n);
     for (int r = 0; r < repeats * (int)variants.size(); ++r) {
         const int variant = variants[r % variants.size()];
-        if (pt_set_kernel_variant(hd, variant) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
+        pt_set_accel(hd, variant >= 1000 ? PT_ACCEL_BRUTE_FORCE : PT_ACCEL_AUTO);
+        if (pt_set_kernel_variant(hd, variant % 1000) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
         pt_reset(hd); pt_reset_counters(hd);
         const auto t0 = std::chrono::steady_clock::now();
         if (pt_run_n(hd, buf, iters, 1) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
@@ -53,6 +57,10 @@ int main(int argc, char **argv)
         printf("scene %d %ux%u it%u d%d v%d: wall %.3f ms kernel %.3f ms  %.3f Gbounces/s  rays %llu  hash %016llx\n",
                scene, w, h, iters, depth, variant, dt * 1e3, ms, rays / (ms * 1e-3) / 1e9,
                (unsigned long long)rays, (unsigned long long)hash);
+        uint64_t st[4];
+        if (pt_accel_stats(hd, st) == PT_OK && st[2])
+            printf("  bvh: %.1f inner nodes + %.1f leaves per ray, %llu rays, %llu unculled\n",
+                   (double)st[0] / st[2], (double)st[1] / st[2], (unsigned long long)st[2], (unsigned long long)st[3]);
     }
     pt_destroy(hd);
     return 0;
