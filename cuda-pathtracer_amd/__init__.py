@@ -65,6 +65,7 @@ ABI = [
     ("pt_set_kernel_variant", _i32, [_vp, _i32]),
     ("pt_set_accel", _i32, [_vp, _i32]),
     ("pt_accel_nodes", _u32, [_vp]),
+    ("pt_set_accel_budget", _i32, [_vp, _u32]),
     ("pt_accel_stats", _i32, [_vp, _pu64]),
     ("pt_last_kernel_ms", _i32, [_vp, _pf]),
     ("pt_read_image", _i32, [_vp, _vp, _vp]),
@@ -280,12 +281,16 @@ class Pathtracer:
         """ACCEL_AUTO: sphere BVH for scenes above 512 spheres; ACCEL_BRUTE_FORCE: linear scan."""
         self._check(self._lib.pt_set_accel(self._h, mode))
 
+    def SetAccelBudget(self, visits: int) -> None:
+        """Visits after which a ray is finished by a wave-wide scan (0: default)."""
+        self._check(self._lib.pt_set_accel_budget(self._h, visits))
+
     def AccelNodes(self) -> int:
         return int(self._lib.pt_accel_nodes(self._h))
 
     def AccelStats(self):
-        """(inner nodes, leaves, rays, rays visiting everything) -- zeros unless built with PT_BVH_STATS."""
-        out = (_u64 * 4)()
+        """The 32 counters of pt_accel_stats -- zeros unless the library was built with PT_BVH_STATS."""
+        out = (_u64 * 32)()
         self._check(self._lib.pt_accel_stats(self._h, out))
         return tuple(int(v) for v in out)
 

@@ -37,6 +37,7 @@ struct pt_context {
     // sphere BVH of scenes too large for LDS residency (device); n_nodes == 0: none
     BvhParams bvh;
     void *d_bvh;          // one allocation behind the pointers in `bvh`
+    uint32_t bvh_default_budget;
     int accel;            // PT_ACCEL_*
     // misc device state
     unsigned long long *d_ray_counter;
@@ -197,6 +198,9 @@ static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sp
     h->bvh.n_nodes = (uint32_t)n_nodes;
     h->bvh.n_big = (uint32_t)n_big;
     h->bvh.depth = d.depth;
+    // A wave-wide scan of n spheres costs about as much as n / 80 divergent box visits.
+    h->bvh_default_budget = n / 80 > 64 ? n / 80 : 64;
+    h->bvh.budget = h->bvh_default_budget;
     for (int a = 0; a < 3; ++a) h->bvh.centre[a] = d.centre[a];
     h->bvh.half_diag = d.half_diag;
     h->bvh.r_min = d.r_min;
@@ -349,14 +353,22 @@ int pt_set_accel(pt_handle h, int mode)
 
 uint32_t pt_accel_nodes(pt_handle h) { return h ? h->bvh.n_nodes : 0; }
 
-int pt_accel_stats(pt_handle h, uint64_t out[4])
+int pt_set_accel_budget(pt_handle h, uint32_t visits)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (!h->scene_ready) return fail(h, PT_ERR_STATE, "pt_set_accel_budget before pt_init_scene");
+    h->bvh.budget = visits ? visits : h->bvh_default_budget;
+    return PT_OK;
+}
+
+int pt_accel_stats(pt_handle h, uint64_t out[32])
 {
     if (!h || !out) return PT_ERR_INVALID;
-    memset(out, 0, 4 * sizeof(uint64_t));
+    memset(out, 0, 32 * sizeof(uint64_t));
     if (!h->d_bvh) return PT_OK;
     PT_HIP(h, hipStreamSynchronize(h->stream));
-    PT_HIP(h, hipMemcpy(out, h->bvh.stats, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    PT_HIP(h, hipMemset(h->bvh.stats, 0, 4 * sizeof(uint64_t)));
+    PT_HIP(h, hipMemcpy(out, h->bvh.stats, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    PT_HIP(h, hipMemset(h->bvh.stats, 0, 32 * sizeof(uint64_t)));
     return PT_OK;
 }
 

@@ -30,9 +30,10 @@ struct BvhParams {
     const int *big_index;
     uint32_t n_nodes, n_big;
     uint32_t depth;           // entries of the per-lane traversal stack
+    uint32_t budget;          // box/leaf visits after which a ray is finished by a wave-wide scan
     float centre[3];
     float half_diag, r_min;
-    unsigned long long *stats;   // 4 counters, written only by -DPT_BVH_STATS builds
+    unsigned long long *stats;   // 32 counters, written only by -DPT_BVH_STATS builds
 };
 
 // Scene, SoA in device memory.

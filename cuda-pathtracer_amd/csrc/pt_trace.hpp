@@ -19,6 +19,12 @@ PT_DEV uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+// Value of `x` in lane `src` (wave-uniform) for every lane.
+PT_DEV float wave_read(float x, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src));
+}
+
 // Bytes of LDS stage_scene<false>() fills, rounded up to 16 (device-side twin of scene_lds_bytes).
 PT_DEV uint32_t scene_lds_bytes_dev(const SceneParams &s)
 {
@@ -93,16 +99,26 @@ PT_DEV void sphere_test_lex(float4 s, int index, V3 o, V3 d, float &tmax, int &b
     }
 }
 
-// Slab test of one child box, widened by `e` on every side, against the ray.  NaN-conservative:
-// fminf / fmaxf drop a NaN operand (0 * inf when the origin lies on a slab plane of an axis the
-// ray does not move along), and the negated comparisons enter a box whose interval is NaN
-// altogether.
-PT_DEV bool slab_test(float lx, float ly, float lz, float hx, float hy, float hz, V3 o, float e, V3 inv,
-                      float tmax, float &tnear, float &tfar)
+// The ray as the slab tests see it: t(plane) = plane * inv + k, with the per-ray widening `e` of
+// the boxes folded into k (klo for lower planes, khi for upper ones).
+struct BvhRay {
+    V3 inv, klo, khi;
+    PT_DEV void widen(V3 o, float e)
+    {
+        klo = mk(-((o.x + e) * inv.x), -((o.y + e) * inv.y), -((o.z + e) * inv.z));
+        khi = mk(-((o.x - e) * inv.x), -((o.y - e) * inv.y), -((o.z - e) * inv.z));
+    }
+};
+
+// Slab test of one child box against the ray.  The fused multiply-adds are deliberate: this
+// arithmetic only decides which boxes are visited (its rounding is covered by the widening),
+// it never reaches a result.  NaN-conservative: the negated comparisons enter on NaN.
+PT_DEV bool slab_test(float lx, float ly, float lz, float hx, float hy, float hz, const BvhRay &r, float tmax,
+                      float &tnear, float &tfar)
 {
-    const float t1x = ((lx - e) - o.x) * inv.x, t2x = ((hx + e) - o.x) * inv.x;
-    const float t1y = ((ly - e) - o.y) * inv.y, t2y = ((hy + e) - o.y) * inv.y;
-    const float t1z = ((lz - e) - o.z) * inv.z, t2z = ((hz + e) - o.z) * inv.z;
+    const float t1x = __builtin_fmaf(lx, r.inv.x, r.klo.x), t2x = __builtin_fmaf(hx, r.inv.x, r.khi.x);
+    const float t1y = __builtin_fmaf(ly, r.inv.y, r.klo.y), t2y = __builtin_fmaf(hy, r.inv.y, r.khi.y);
+    const float t1z = __builtin_fmaf(lz, r.inv.z, r.klo.z), t2z = __builtin_fmaf(hz, r.inv.z, r.khi.z);
     tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
                             __builtin_fminf(t1z, t2z));
     tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
@@ -123,24 +139,50 @@ struct BvhMargin {
     }
 };
 
-// One child box: widened for hits anywhere up to T0 first; rays whose direction is noticeably
-// longer than 1 then narrow the widening to what hits inside this box can need (their t cannot
-// exceed the exit distance of the widely widened box) and test again.
-PT_DEV bool bvh_box_test(float lx, float ly, float lz, float hx, float hy, float hz, V3 o, V3 inv, float e0,
-                         bool refine, const BvhMargin &m, float tmax, float &tnear)
+// One child box: widened for hits anywhere up to T0 first (`ray`, widening e0); rays whose
+// direction is noticeably longer than 1 then narrow the widening to what hits inside this box
+// can need (their t cannot exceed the exit distance of the widely widened box) and test again.
+PT_DEV bool bvh_box_test(float lx, float ly, float lz, float hx, float hy, float hz, const BvhRay &ray, V3 o,
+                         float e0, bool refine, const BvhMargin &m, float tmax, float &tnear)
 {
     float tfar;
-    bool hit = slab_test(lx, ly, lz, hx, hy, hz, o, e0, inv, tmax, tnear, tfar);
+    bool hit = slab_test(lx, ly, lz, hx, hy, hz, ray, tmax, tnear, tfar);
     if (hit && refine) {
         const float e1 = m.at(__builtin_fminf(tfar * 1.00001f, tmax));
-        if (e1 < e0) hit = slab_test(lx, ly, lz, hx, hy, hz, o, e1, inv, tmax, tnear, tfar);
+        if (e1 < e0) {
+            BvhRay narrow;
+            narrow.inv = ray.inv;
+            narrow.widen(o, e1);
+            hit = slab_test(lx, ly, lz, hx, hy, hz, narrow, tmax, tnear, tfar);
+        }
     }
     return hit;
+}
+
+// 1 / x for the slab tests, finite for every finite or zero x (a zero component becomes a tiny
+// one: the ray then leaves the scene's extent along that axis only after ~1e18 units).
+PT_DEV float bvh_inverse(float x)
+{
+    const float a = __builtin_fabsf(x) > 1e-18f ? x : __builtin_copysignf(1e-18f, x);
+    return __builtin_amdgcn_rcpf(a);
+}
+
+// Pops deferred boxes until one can still hold a hit at or below tmax; false when none is left.
+PT_DEV bool bvh_pop(const uint2 *stack, int &sp, float tmax, int &cur)
+{
+    while (sp > 0) {
+        --sp;
+        const uint2 top = stack[sp * kBlockThreads];
+        if (!(__uint_as_float(top.y) > tmax)) { cur = (int)top.x; return true; }
+    }
+    return false;
 }
 
 // Nearest hit through the sphere BVH (host side: pt_bvh.cpp).  Depth-first, nearer child first,
 // the farther one deferred on a per-lane stack in LDS (`stack`, [B.depth][kBlockThreads]) together
 // with its entry distance, so that it is dropped when a closer hit has been found meanwhile.
+// The loop alternates between "descend until this lane holds a leaf" and "test the leaf", so
+// that the lanes of a wave run the box code together and the sphere code together.
 // A box is entered when the ray's slab interval through the widened box overlaps [0, tmax].
 // The widening is per ray: a valid t of the fp32 sphere test puts origin + t * dir at squared
 // distance r^2 + (|dir|^2 - 1) * t^2 + err from the centre, err < 1e-6 * |op|^2 * |dir|^2, op =
@@ -152,55 +194,79 @@ PT_DEV bool bvh_box_test(float lx, float ly, float lz, float hx, float hy, float
 // below (2 |dir| + 0.1) L: the hit lies about r from a centre, and |op| + r <= L.
 // A skipped box therefore cannot hold a sphere whose test would succeed with t <= tmax, and
 // sphere_test_lex makes the visiting order irrelevant: the result equals the brute-force scan's.
-PT_DEV void intersect_bvh(const BvhParams &B, uint2 *stack, int tid, V3 o, V3 d, float &tmax, int &best)
+//
+// Visit budget: a few rays (long mirror directions widen their boxes enormously) would visit
+// thousands of boxes and hold their whole wave up.  A lane that exceeds B.budget visits stops
+// with its partial result -- a valid candidate, the lexicographic minimum does not care about
+// order -- and the wave then finishes such rays together, one at a time: 64 lanes scan the sphere
+// array in stride and reduce (t, index) across the wave.  Every lane of the wave must call this
+// function (`active` masks the lanes that carry a ray).
+PT_DEV void intersect_bvh(const BvhParams &B, const float4 *sph, uint32_t n_prims, uint2 *stack, int tid,
+                          bool active, V3 o, V3 d, float &tmax, int &best)
 {
-    for (uint32_t i = 0; i < B.n_big; ++i) sphere_test_lex(B.big_sph[i], B.big_index[i], o, d, tmax, best);
-    const float cx = o.x - B.centre[0], cy = o.y - B.centre[1], cz = o.z - B.centre[2];
-    const float L = __builtin_sqrtf(cx * cx + cy * cy + cz * cz) * 1.000001f + B.half_diag;
-    const float excess = (d.x * d.x + d.y * d.y + d.z * d.z) - 1.f;
-    // a NaN in the origin or the direction makes every sphere test fail (all comparisons false)
-    if (excess != excess || L != L) return;
+    bool more = active;
+    float e = 0.f;
+    bool refine = false;
     BvhMargin m;
-    m.eps = __builtin_fmaxf(excess, 0.f) * 1.000001f + 4e-7f;
-    // b = op . dir grows with |dir|, and with it the rounding errors of b * b and of t = b -+ sqrt(det)
-    m.err = 1e-6f * L * L * (1.f + m.eps);
-    m.slack = 2e-6f * L * (1.f + m.eps);
-    m.r_min = B.r_min;
-    float e = m.at(__builtin_fminf(tmax, (2.2f * (1.f + m.eps) + 0.1f) * L));
-    bool refine = m.eps > 2e-6f;
-    // overflow (absurdly long directions, far origins): visit everything, like the scan
-    if (!(e < 3.0e38f)) { e = PT_INF; refine = false; }
-    const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    BvhRay ray;
+    if (active) {
+        for (uint32_t i = 0; i < B.n_big; ++i) sphere_test_lex(B.big_sph[i], B.big_index[i], o, d, tmax, best);
+        const float cx = o.x - B.centre[0], cy = o.y - B.centre[1], cz = o.z - B.centre[2];
+        const float L = __builtin_sqrtf(cx * cx + cy * cy + cz * cz) * 1.000001f + B.half_diag;
+        const float excess = (d.x * d.x + d.y * d.y + d.z * d.z) - 1.f;
+        // a NaN in the origin or the direction makes every sphere test fail (all comparisons false)
+        if (excess != excess || L != L) more = false;
+        m.eps = __builtin_fmaxf(excess, 0.f) * 1.000001f + 4e-7f;
+        // b = op . dir grows with |dir|, and with it the rounding errors of b * b and of t = b -+ sqrt(det)
+        m.err = 1e-6f * L * L * (1.f + m.eps);
+        // slab arithmetic: plane * inv + k cancels two terms of the size of the coordinates
+        m.slack = (2e-6f * L + 4e-7f * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z))) * (1.f + m.eps);
+        m.r_min = B.r_min;
+        e = m.at(__builtin_fminf(tmax, (2.2f * (1.f + m.eps) + 0.1f) * L));
+        refine = m.eps > 2e-6f;
+        // overflow (absurdly long directions, far origins): visit everything, like the scan
+        if (!(e < 3.0e38f)) { e = PT_INF; refine = false; }
+        ray.inv = mk(bvh_inverse(d.x), bvh_inverse(d.y), bvh_inverse(d.z));
+        ray.widen(o, e);
+    }
     stack += tid;
     int cur = 0, sp = 0;
+    uint32_t visits = 0;
+    bool over_budget = false;
 #ifdef PT_BVH_STATS
-    uint32_t st_nodes = 0, st_leaves = 0;
+    uint32_t st_nodes = 0, st_leaves = 0, st_wave_nodes = 0, st_wave_leaves = 0;
+    const bool st_leader = (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1;
 #define PT_BVH_COUNT(x) (++(x))
+#define PT_BVH_WAVE_COUNT(x) do { if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) ++(x); } while (0)
 #else
 #define PT_BVH_COUNT(x) ((void)0)
+#define PT_BVH_WAVE_COUNT(x) ((void)0)
 #endif
-    for (;;) {
-        if (cur >= 0) {
+    while (more) {
+        while (more && cur >= 0) {
             PT_BVH_COUNT(st_nodes);
+            PT_BVH_WAVE_COUNT(st_wave_nodes);
             const float4 *N = B.nodes + 4 * (size_t)cur;
             const float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
             float tn0, tn1;
-            const bool hit0 = bvh_box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, inv, e, refine, m, tmax, tn0);
-            const bool hit1 = bvh_box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, inv, e, refine, m, tmax, tn1);
+            const bool hit0 = bvh_box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, o, e, refine, m, tmax, tn0);
+            const bool hit1 = bvh_box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, o, e, refine, m, tmax, tn1);
             const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
             if (hit0 && hit1) {
                 const bool first0 = tn0 <= tn1;
                 stack[sp * kBlockThreads] = make_uint2((uint32_t)(first0 ? c1 : c0), __float_as_uint(first0 ? tn1 : tn0));
                 ++sp;
                 cur = first0 ? c0 : c1;
-                continue;
-            }
-            if (hit0 || hit1) {
+            } else if (hit0 || hit1) {
                 cur = hit0 ? c0 : c1;
-                continue;
+            } else {
+                more = bvh_pop(stack, sp, tmax, cur);
             }
-        } else {
+            if (++visits > B.budget) { over_budget = more; more = false; }
+        }
+        if (more) {
             PT_BVH_COUNT(st_leaves);
+            PT_BVH_WAVE_COUNT(st_wave_leaves);
             const uint32_t leaf = (uint32_t)~cur;
             const float4 *S = B.leaf_sph + 4 * (size_t)leaf;
             const float4 s0 = S[0], s1 = S[1], s2 = S[2], s3 = S[3];
@@ -209,27 +275,47 @@ PT_DEV void intersect_bvh(const BvhParams &B, uint2 *stack, int tid, V3 o, V3 d,
             sphere_test_lex(s1, id.y, o, d, tmax, best);
             sphere_test_lex(s2, id.z, o, d, tmax, best);
             sphere_test_lex(s3, id.w, o, d, tmax, best);
-        }
-        // next deferred box that can still hold a hit at or below tmax
-        for (;;) {
-            if (sp == 0) {
-#ifdef PT_BVH_STATS
-                atomicAdd(B.stats + 0, (unsigned long long)st_nodes);
-                atomicAdd(B.stats + 1, (unsigned long long)st_leaves);
-                atomicAdd(B.stats + 2, 1ull);
-                if (!(e < PT_INF)) atomicAdd(B.stats + 3, 1ull);
-#endif
-                return;
-            }
-            --sp;
-            const uint2 top = stack[sp * kBlockThreads];
-            if (!(__uint_as_float(top.y) > tmax)) { cur = (int)top.x; break; }
+            more = bvh_pop(stack, sp, tmax, cur);
+            ++visits;
         }
     }
+    // rays over budget: the wave scans all spheres for each of them in turn
+    unsigned long long pending = __ballot(over_budget);
+    const uint32_t lane = __lane_id();
+    while (pending) {
+        const int src = __ffsll(pending) - 1;
+        pending &= pending - 1;
+        const V3 so = mk(wave_read(o.x, src), wave_read(o.y, src), wave_read(o.z, src));
+        const V3 sd = mk(wave_read(d.x, src), wave_read(d.y, src), wave_read(d.z, src));
+        float ct = wave_read(tmax, src);
+        int cb = __float_as_int(wave_read(__int_as_float(best), src));
+        for (uint32_t i = lane; i < n_prims; i += 64) sphere_test_lex(sph[i], (int)i, so, sd, ct, cb);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float t2 = __shfl_xor(ct, off);
+            const int b2 = __shfl_xor(cb, off);
+            // a miss carries index -1: as unsigned it loses against every hit at the same t
+            if (t2 < ct || (t2 == ct && (uint32_t)b2 < (uint32_t)cb)) { ct = t2; cb = b2; }
+        }
+        if ((int)lane == src) { tmax = ct; best = cb; }
+    }
+#ifdef PT_BVH_STATS
+    if (active) {
+        atomicAdd(B.stats + 0, (unsigned long long)st_nodes);
+        atomicAdd(B.stats + 1, (unsigned long long)st_leaves);
+        atomicAdd(B.stats + 2, 1ull);
+        if (over_budget) atomicAdd(B.stats + 3, 1ull);
+        atomicAdd(B.stats + 4, (unsigned long long)st_wave_nodes);
+        atomicAdd(B.stats + 5, (unsigned long long)st_wave_leaves);
+        if (refine) atomicAdd(B.stats + 7, 1ull);
+        atomicAdd(B.stats + 8 + (31 - __clz((int)(st_nodes + st_leaves + 1))), 1ull);   // log2 histogram of steps
+    }
+    if (st_leader) atomicAdd(B.stats + 6, 1ull);
+#endif
 }
 
-// Intersect (scene.h:71-94).  With TILED (and not BVH) every thread of the workgroup must call
-// it (barriers); `active` masks the lanes that actually carry a ray.
+// Intersect (scene.h:71-94).  With TILED every thread of the workgroup must call it (barriers in
+// the scan, wave-wide cooperation in the BVH search); `active` masks the lanes that carry a ray.
 template <bool TILED, bool BVH = false>
 PT_DEV void intersect_scene(const SceneParams &p, const SceneView &sc, unsigned char *lds_raw, int tid,
                             bool active, V3 o, V3 d, float &tmax, int &best)
@@ -237,7 +323,7 @@ PT_DEV void intersect_scene(const SceneParams &p, const SceneView &sc, unsigned 
     tmax = PT_INF;
     best = -1;
     if (BVH) {
-        if (active) intersect_bvh(p.bvh, reinterpret_cast<uint2 *>(lds_raw), tid, o, d, tmax, best);
+        intersect_bvh(p.bvh, p.sph, p.n_prims, reinterpret_cast<uint2 *>(lds_raw), tid, active, o, d, tmax, best);
     } else if (TILED) {
         float4 *lds_sph = reinterpret_cast<float4 *>(lds_raw);
         for (uint32_t base = 0; base < p.n_prims; base += kTileSpheres) {

@@ -160,10 +160,18 @@ int pt_set_kernel_variant(pt_handle h, int variant);
 enum { PT_ACCEL_AUTO = 0, PT_ACCEL_BRUTE_FORCE = 1 };
 int pt_set_accel(pt_handle h, int mode);
 uint32_t pt_accel_nodes(pt_handle h);
-/* Traversal counters since the last call: inner nodes visited, leaves visited, rays traversed,
- * rays that had to visit everything.  Only libraries built with -DPT_BVH_STATS count (the
- * counting costs time); others return zeros. */
-int pt_accel_stats(pt_handle h, uint64_t out[4]);
+/* A ray that has visited more than `visits` boxes and leaves stops descending and is finished
+ * by its whole wave scanning all spheres (same result; bounds the cost of the few rays whose
+ * boxes must be widened enormously).  0 restores the default, max(64, spheres / 80), set by
+ * pt_init_scene.  A tuning and test knob. */
+int pt_set_accel_budget(pt_handle h, uint32_t visits);
+/* Traversal counters since the last call (only libraries built with -DPT_BVH_STATS count -- the
+ * counting costs time -- others return zeros):
+ *   [0] inner nodes visited  [1] leaves visited  [2] rays traversed  [3] rays finished by the wave-wide scan
+ *   [4] inner-node iterations and [5] leaf iterations summed over waves (a wave iterates until
+ *   its slowest lane is done)  [6] wave-level traversals  [7] rays with a direction longer than 1
+ *   [8 + k] rays whose visit count n satisfies 2^k <= n + 1 < 2^(k+1) */
+int pt_accel_stats(pt_handle h, uint64_t out[32]);
 /* HIP-event time of the last pt_run/pt_run_n launch in milliseconds (waits for it). */
 int pt_last_kernel_ms(pt_handle h, float *ms);
 

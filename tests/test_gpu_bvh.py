@@ -191,6 +191,32 @@ def test_scene_the_builder_declines_falls_back_to_the_scan(pt, O, torch_cuda):
     assert img.tobytes() == ref.tobytes()
 
 
+@pytest.mark.parametrize("budget", [1, 7, 40, 10**9])
+def test_visit_budget_does_not_change_results(pt, O, torch_cuda, budget):
+    """Budget 1: practically every ray is finished by the wave-wide scan; 10^9: none is."""
+    rng = np.random.default_rng(21)
+    mats = materials(pt, [(0, 0.0), (1, 0.9), (2, 1.33), (0, 0.0)])
+    walls, lights = room(pt, (0, 40, -20), 60)
+    sph = np.concatenate([walls, cloud(pt, rng, 1200, (0, 40, -20), 50, 0.5, 3.0, 4)])
+    cam = pt.Camera([0, 45, 35], [0, 38, -20], [0, 1, 0], 96, 64, 0, 0, 60.0)
+    ref, ref_hits, ref_rad, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, 5, 8, n_iterations=2,
+                                                       want_paths=True, n_threads=8)
+    for variant in (0, pt.VARIANT_WAVEFRONT):
+        tr = pt.Pathtracer(cam, 8, 5)
+        tr.Init(mats, sph, lights)
+        assert tr.AccelNodes() > 0
+        tr.SetAccelBudget(budget)
+        tr.SetKernelVariant(variant)
+        tr.ResetCounters()
+        img = render(torch_cuda, tr, 1, 2).cpu().numpy()
+        assert tr.RayCount() == ref_rays
+        assert img.tobytes() == ref.tobytes(), (budget, variant)
+        hits, rad, _, _ = tr.DebugTrace(0, 0, 96, 64, 2)
+        assert np.array_equal(hits, ref_hits[1])
+        assert rad.tobytes() == ref_rad[1].tobytes()
+        tr.Release()
+
+
 def test_small_scenes_have_no_bvh(pt, torch_cuda):
     mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_MIXED)
     tr = pt.Pathtracer(pt.Camera(eye, look, up, 32, 32, 0, 0, fov), 4, 1)

@@ -57,10 +57,16 @@ int main(int argc, char **argv)
         printf("scene %d %ux%u it%u d%d v%d: wall %.3f ms kernel %.3f ms  %.3f Gbounces/s  rays %llu  hash %016llx\n",
                scene, w, h, iters, depth, variant, dt * 1e3, ms, rays / (ms * 1e-3) / 1e9,
                (unsigned long long)rays, (unsigned long long)hash);
-        uint64_t st[4];
-        if (pt_accel_stats(hd, st) == PT_OK && st[2])
-            printf("  bvh: %.1f inner nodes + %.1f leaves per ray, %llu rays, %llu unculled\n",
-                   (double)st[0] / st[2], (double)st[1] / st[2], (unsigned long long)st[2], (unsigned long long)st[3]);
+        uint64_t st[32];
+        if (pt_accel_stats(hd, st) == PT_OK && st[2]) {
+            printf("  bvh: %.1f inner nodes + %.1f leaves per ray, %llu rays, %llu over budget, %llu long-direction\n",
+                   (double)st[0] / st[2], (double)st[1] / st[2], (unsigned long long)st[2],
+                   (unsigned long long)st[3], (unsigned long long)st[7]);
+            printf("  per wave traversal (%llu): %.1f inner + %.1f leaf iterations\n  visits histogram (log2):",
+                   (unsigned long long)st[6], (double)st[4] / st[6], (double)st[5] / st[6]);
+            for (int k = 0; k < 16; ++k) printf(" %llu", (unsigned long long)st[8 + k]);
+            printf("\n");
+        }
     }
     pt_destroy(hd);
     return 0;
