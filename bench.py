@@ -49,6 +49,19 @@ def flops_per_ray(n_spheres: int) -> int:
     return 17 * n_spheres + 121
 
 
+def flops_per_ray_bvh(workload: str):
+    """With the sphere BVH the work per Intersect call depends on the ray: the average visit
+    counts come from the committed run of the counting build (tools/stats, pt_accel_stats):
+    44 flops per inner node (two boxes: 6 fma + 10 min/max each), 4 sphere tests per leaf, plus
+    the always-tested spheres and the bounce's shading.  None when no count is committed."""
+    path = os.path.join(ROOT, "profiles", f"bvh_visits_{workload}.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        v = json.load(f)
+    return 121 + 17 * v["always_tested_spheres"] + 44 * v["inner_per_ray"] + 4 * 17 * v["leaves_per_ray"]
+
+
 def cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render=None):
     """Time the CPU oracle on a bounded sample of the same workload (about 10-30 s of CPU work).
     gpu_render(n_iterations) -> numpy image: when given, the oracle's rows are also compared with
@@ -103,6 +116,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="demo1080", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 regeneration, 1 classic)")
+    ap.add_argument("--accel", default="auto", choices=["auto", "brute"],
+                    help="scenes above 512 spheres: sphere BVH (auto) or the reference's linear scan (brute)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -136,6 +151,8 @@ def main():
     tr = pt.Pathtracer(cam, wl["depth"], seed=1)
     tr.Init(mats, sph, lights)
     tr.SetKernelVariant(args.variant)
+    tr.SetAccel(pt.ACCEL_AUTO if args.accel == "auto" else pt.ACCEL_BRUTE_FORCE)
+    bvh = args.accel == "auto" and tr.AccelNodes() > 0
     tr.SetStream(torch.cuda.current_stream().cuda_stream)
     if world > 1:
         tr.SetAccumMode(pt.ACCUM_SUM)
@@ -192,15 +209,15 @@ def main():
     # library's own event pair around the last launch is used instead.
     launch_ms = region_ms / args.steps if world == 1 else tr.LastKernelMs()
     rays_per_launch = rays_local / max(1, args.steps)
-    fpr = flops_per_ray(len(sph))
+    fpr = flops_per_ray_bvh(args.workload) if bvh else flops_per_ray(len(sph))
     # HBM bytes per step from the committed PMC passes of this same command (rocprofv3 cannot be
     # run from inside the benchmark): profiles/pmc_traffic_<workload>_v<variant>.json
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}_v{args.variant}.json")
+    tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}{'_bvh' if bvh else ''}_v{args.variant}.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f).get("hbm_bytes_per_step")
-    achieved = rays_per_launch * fpr / (launch_ms * 1e-3) / 1e12
+    achieved = rays_per_launch * fpr / (launch_ms * 1e-3) / 1e12 if fpr else None
 
     if rank == 0:
         out = {
@@ -217,9 +234,11 @@ def main():
             "config": {"workload": wl["label"], "paths_per_step_per_gpu": wl["width"] * wl["height"] * 4 * n_it,
                        "bounces_per_step_per_gpu": rays_per_launch, "spheres": int(len(sph)),
                        "parallelism": "single" if world == 1 else f"sample-range split x{world} + RCCL reduce(sum)",
-                       "kernel_variant": args.variant},
+                       "kernel_variant": args.variant,
+                       "nearest_hit": "sphere BVH" if bvh else "linear scan"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS if achieved else None,
+                         "traffic": traffic,
                          "kernel": "render_kernel", "launch_ms": launch_ms,
                          "flops_per_bounce": fpr, "bounces_per_launch": rays_per_launch},
         }
