@@ -63,6 +63,8 @@ ABI = [
     ("pt_ray_count", _i32, [_vp, _pu64]),
     ("pt_reset_counters", _i32, [_vp]),
     ("pt_set_kernel_variant", _i32, [_vp, _i32]),
+    ("pt_save_checkpoint", _i32, [_vp, _vp, ctypes.c_char_p]),
+    ("pt_load_checkpoint", _i32, [_vp, _vp, ctypes.c_char_p]),
     ("pt_set_accel", _i32, [_vp, _i32]),
     ("pt_accel_nodes", _u32, [_vp]),
     ("pt_set_accel_budget", _i32, [_vp, _u32]),
@@ -311,6 +313,14 @@ class Pathtracer:
         out = np.empty((self.height, self.width, 3), np.float32)
         self._check(self._lib.pt_read_image(self._h, _vp(_devptr(dev_buffer, self)), _ptr(out)))
         return out
+
+    def SaveCheckpoint(self, dev_buffer, path: str) -> None:
+        """Frame buffer + iteration + seed/depth/size to `path`; see LoadCheckpoint."""
+        self._check(self._lib.pt_save_checkpoint(self._h, _vp(_devptr(dev_buffer, self)), os.fsencode(path)))
+
+    def LoadCheckpoint(self, dev_buffer, path: str) -> None:
+        """Restores frame buffer and iteration counter; the next Run continues the render bit-exactly."""
+        self._check(self._lib.pt_load_checkpoint(self._h, _vp(_devptr(dev_buffer, self)), os.fsencode(path)))
 
     def DebugTrace(self, x0: int, y0: int, x1: int, y1: int, iteration: int):
         """Returns (hit_ids[h,w,4,mb+1], radiance[h,w,4,3], pixel_rgb[h,w,3], ray_count)."""

@@ -581,6 +581,75 @@ int pt_read_image(pt_handle h, const float *device_buffer, float *host_rgb)
     return PT_OK;
 }
 
+// ---- checkpoint / resume ---------------------------------------------------------------------
+// File: 64-byte header + width*height*3 floats.  With the counter-based RNG the triple
+// (frame buffer, iteration, seed) is the whole state of a render.
+namespace {
+struct CheckpointHeader {
+    char magic[8];        // "PTMICKP1"
+    uint32_t width, height;
+    uint32_t iteration;
+    int32_t max_bounces;
+    uint64_t seed;
+    int32_t accum_mode;
+    uint32_t reserved[7];
+};
+static_assert(sizeof(CheckpointHeader) == 64, "checkpoint header layout");
+const char kCheckpointMagic[8] = {'P', 'T', 'M', 'I', 'C', 'K', 'P', '1'};
+}
+
+int pt_save_checkpoint(pt_handle h, const float *device_buffer, const char *path)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (!device_buffer || !path) return fail(h, PT_ERR_INVALID, "pt_save_checkpoint: NULL argument");
+    const size_t n = (size_t)h->camera.width * h->camera.height * 3;
+    std::vector<float> img(n);
+    const int rc = pt_read_image(h, device_buffer, img.data());
+    if (rc != PT_OK) return rc;
+    CheckpointHeader hd;
+    memset(&hd, 0, sizeof hd);
+    memcpy(hd.magic, kCheckpointMagic, 8);
+    hd.width = h->camera.width; hd.height = h->camera.height;
+    hd.iteration = h->iteration;
+    hd.max_bounces = h->max_bounces;
+    hd.seed = h->seed;
+    hd.accum_mode = h->accum_mode;
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(h, PT_ERR_INVALID, "pt_save_checkpoint: cannot open %s for writing", path);
+    const bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && fwrite(img.data(), sizeof(float), n, f) == n;
+    if (fclose(f) != 0 || !ok) return fail(h, PT_ERR_INVALID, "pt_save_checkpoint: short write to %s", path);
+    return PT_OK;
+}
+
+int pt_load_checkpoint(pt_handle h, float *device_buffer, const char *path)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (!device_buffer || !path) return fail(h, PT_ERR_INVALID, "pt_load_checkpoint: NULL argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(h, PT_ERR_INVALID, "pt_load_checkpoint: cannot open %s", path);
+    CheckpointHeader hd;
+    const size_t n = (size_t)h->camera.width * h->camera.height * 3;
+    std::vector<float> img(n);
+    bool ok = fread(&hd, sizeof hd, 1, f) == 1;
+    const bool header_ok = ok && memcmp(hd.magic, kCheckpointMagic, 8) == 0;
+    const bool same = header_ok && hd.width == h->camera.width && hd.height == h->camera.height &&
+                      hd.max_bounces == h->max_bounces && hd.seed == h->seed && hd.accum_mode == h->accum_mode;
+    if (same) ok = fread(img.data(), sizeof(float), n, f) == n && fgetc(f) == EOF;
+    fclose(f);
+    if (!header_ok) return fail(h, PT_ERR_INVALID, "pt_load_checkpoint: %s is not a checkpoint", path);
+    if (!same)
+        return fail(h, PT_ERR_STATE, "pt_load_checkpoint: %s is %ux%u, depth %d, seed %llu, mode %d; this instance "
+                    "is %ux%u, depth %d, seed %llu, mode %d", path, hd.width, hd.height, hd.max_bounces,
+                    (unsigned long long)hd.seed, hd.accum_mode, h->camera.width, h->camera.height, h->max_bounces,
+                    (unsigned long long)h->seed, h->accum_mode);
+    if (!ok) return fail(h, PT_ERR_INVALID, "pt_load_checkpoint: %s is truncated or has trailing bytes", path);
+    PT_HIP(h, hipMemcpyAsync(device_buffer, img.data(), n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    h->iteration = hd.iteration;
+    h->fresh = hd.iteration == 0;
+    return PT_OK;
+}
+
 int pt_ray_count(pt_handle h, uint64_t *out)
 {
     if (!h || !out) return PT_ERR_INVALID;

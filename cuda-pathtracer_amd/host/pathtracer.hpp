@@ -169,6 +169,15 @@ public:
     }
     void Reset() { check(pt_reset(handle_)); }
     uint32_t GetIteration() const { return pt_iteration(handle_); }
+    // Not in the reference: n Run() calls in one launch, checkpoint files, nearest-hit search mode.
+    void RunN(float *devBuffer, uint32_t n)
+    {
+        check(pt_set_camera(handle_, &camera_->Pod()));
+        check(pt_run_n(handle_, devBuffer, n, 1));
+    }
+    void SaveCheckpoint(const float *devBuffer, const std::string &path) { check(pt_save_checkpoint(handle_, devBuffer, path.c_str())); }
+    void LoadCheckpoint(float *devBuffer, const std::string &path) { check(pt_load_checkpoint(handle_, devBuffer, path.c_str())); }
+    void SetAccel(int mode) { check(pt_set_accel(handle_, mode)); }
     void Release()
     {
         if (handle_) { pt_destroy(handle_); handle_ = nullptr; }

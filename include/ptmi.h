@@ -179,6 +179,14 @@ int pt_last_kernel_ms(pt_handle h, float *ms);
  * the caller divides by the number of iterations. */
 int pt_read_image(pt_handle h, const float *device_buffer, float *host_rgb);
 
+/* Checkpoint / resume (no counterpart: the reference's state is `iteration` and the frame
+ * buffer, pathtracer.h:58, and is lost with the window).  The file holds the frame buffer, the
+ * iteration counter, seed, depth, size and accumulation mode; loading into an instance created
+ * with different values fails with PT_ERR_STATE.  Scene and camera are the caller's to restore.
+ * A render resumed from a checkpoint is bit-identical to an uninterrupted one. */
+int pt_save_checkpoint(pt_handle h, const float *device_buffer, const char *path);
+int pt_load_checkpoint(pt_handle h, float *device_buffer, const char *path);
+
 /* Parity hook: traces iteration `iteration` of the pixel rectangle [x0,x1) x [y0,y1) with the
  * production device functions and returns, per path ([pixel row-major][sub-sample 0..3]):
  *   hit_ids  [..][max_bounces+1] int32  primitive index of the k-th Intersect call

@@ -215,6 +215,53 @@ def test_sample_range_split_sums_to_the_mean(pt, torch_cuda):
     np.testing.assert_allclose(total.cpu().numpy() / n, g["image"].ravel(), rtol=2e-6 * np.sqrt(n), atol=1e-6)
 
 
+def test_checkpoint_resume_is_bit_exact(pt, torch_cuda, tmp_path):
+    """2 iterations, save, new instance, load, 2 more == 4 uninterrupted (golden), in both
+    accumulation modes; mismatching instances and damaged files are refused."""
+    g = load_golden("demo_64x48_d8_it1-4")
+    path = str(tmp_path / "render.ckp")
+    for mode in (pt.ACCUM_RUNNING_MEAN, pt.ACCUM_SUM):
+        full = make_tracer(pt, g)
+        full.SetAccumMode(mode)
+        whole = render(torch_cuda, full, 1, 4)
+        full.Release()
+        a = make_tracer(pt, g)
+        a.SetAccumMode(mode)
+        buf = render(torch_cuda, a, 1, 2)
+        a.SaveCheckpoint(buf, path)
+        a.Release()
+        b = make_tracer(pt, g)
+        b.SetAccumMode(mode)
+        buf2 = torch_cuda.full((64 * 48 * 3,), -1.0, device="cuda")
+        b.LoadCheckpoint(buf2, path)
+        assert b.GetIteration() == 2
+        b.RunN(buf2, 2)
+        assert b.GetIteration() == 4
+        assert torch_cuda.equal(buf2, whole)
+        if mode == pt.ACCUM_RUNNING_MEAN:
+            assert buf2.cpu().numpy().tobytes() == g["image"].tobytes()
+        b.Release()
+    other = pt.Pathtracer(g["camera_pod"], int(g["max_bounces"]), int(g["seed"]) + 1)
+    other.Init(g["materials"], g["spheres"], g["lights"])
+    other.SetAccumMode(pt.ACCUM_SUM)
+    with pytest.raises(pt.PtError) as e:
+        other.LoadCheckpoint(buf2, path)          # different seed
+    assert e.value.code == pt.PT_ERR_STATE and "seed" in str(e.value)
+    blob = open(path, "rb").read()
+    open(path, "wb").write(blob[:-5])
+    c = make_tracer(pt, g)
+    c.SetAccumMode(pt.ACCUM_SUM)
+    with pytest.raises(pt.PtError):
+        c.LoadCheckpoint(buf2, path)              # truncated
+    open(path, "wb").write(b"not a checkpoint" * 8)
+    with pytest.raises(pt.PtError):
+        c.LoadCheckpoint(buf2, path)
+    with pytest.raises(pt.PtError):
+        c.LoadCheckpoint(buf2, str(tmp_path / "missing.ckp"))
+    assert c.GetIteration() == 0                  # failed loads leave the instance alone
+    c.Release(); other.Release()
+
+
 def test_camera_update_takes_effect_next_run(pt, torch_cuda):
     g = load_golden("demo_64x64_d4_it1")
     tr = make_tracer(pt, g)
