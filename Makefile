@@ -15,9 +15,9 @@ CSRC     := $(PKG)/csrc
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
             -fhip-fp32-correctly-rounded-divide-sqrt -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
-SRCS := $(CSRC)/pt_kernels.hip $(CSRC)/pt_wavefront.hip $(CSRC)/pt_api.cpp $(CSRC)/pt_scene.cpp \
+SRCS := $(CSRC)/pt_kernels.hip $(CSRC)/pt_wavefront.hip $(CSRC)/pt_nee.hip $(CSRC)/pt_api.cpp $(CSRC)/pt_scene.cpp \
         $(CSRC)/pt_bvh.cpp
-HDRS := include/ptmi.h $(CSRC)/pt_kernels.hpp $(CSRC)/pt_device.hpp $(CSRC)/pt_trace.hpp $(CSRC)/pt_bvh.hpp
+HDRS := include/ptmi.h $(CSRC)/pt_kernels.hpp $(CSRC)/pt_device.hpp $(CSRC)/pt_trace.hpp $(CSRC)/pt_bvh.hpp $(CSRC)/pt_nee.hpp
 
 all: lib oracle
 

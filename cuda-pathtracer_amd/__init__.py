@@ -41,6 +41,7 @@ HIT_MISS, HIT_NOT_TRACED = -1, -2
 SCENE_DEMO, SCENE_SYNTH10K, SCENE_MIXED = 0, 1, 2
 VARIANT_REGENERATION, VARIANT_CLASSIC, VARIANT_WAVEFRONT = 0, 1, 100
 ACCEL_AUTO, ACCEL_BRUTE_FORCE = 0, 1
+INTEGRATOR_PATH, INTEGRATOR_NEE_MIS = 0, 1
 PT_OK, PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_DEVICE, PT_ERR_NOMEM = 0, -1, -2, -3, -4
 
 # Every symbol include/ptmi.h declares: (name, restype, argtypes)
@@ -65,6 +66,7 @@ ABI = [
     ("pt_set_kernel_variant", _i32, [_vp, _i32]),
     ("pt_save_checkpoint", _i32, [_vp, _vp, ctypes.c_char_p]),
     ("pt_load_checkpoint", _i32, [_vp, _vp, ctypes.c_char_p]),
+    ("pt_set_integrator", _i32, [_vp, _i32]),
     ("pt_set_accel", _i32, [_vp, _i32]),
     ("pt_accel_nodes", _u32, [_vp]),
     ("pt_set_accel_budget", _i32, [_vp, _u32]),
@@ -278,6 +280,10 @@ class Pathtracer:
 
     def SetKernelVariant(self, variant: int) -> None:
         self._check(self._lib.pt_set_kernel_variant(self._h, variant))
+
+    def SetIntegrator(self, integrator: int) -> None:
+        """INTEGRATOR_PATH: the reference's Trace; INTEGRATOR_NEE_MIS: plus direct-light sampling."""
+        self._check(self._lib.pt_set_integrator(self._h, integrator))
 
     def SetAccel(self, mode: int) -> None:
         """ACCEL_AUTO: sphere BVH for scenes above 512 spheres; ACCEL_BRUTE_FORCE: linear scan."""

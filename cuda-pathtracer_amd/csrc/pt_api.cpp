@@ -30,8 +30,9 @@ struct pt_context {
     hipStream_t stream;
     int device;
     // scene (device)
-    float4 *d_sph, *d_aux, *d_mat, *d_light;
+    float4 *d_sph, *d_aux, *d_mat, *d_light, *d_light_geom;
     int *d_mat_type;
+    int integrator;       // PT_INTEGRATOR_*
     uint32_t n_prims, n_mats, n_lights;
     bool scene_ready;
     // sphere BVH of scenes too large for LDS residency (device); n_nodes == 0: none
@@ -119,8 +120,9 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->small_scene_opts = 1;
     h->stream = nullptr;
     h->device = dev;
-    h->d_sph = h->d_aux = h->d_mat = h->d_light = nullptr;
+    h->d_sph = h->d_aux = h->d_mat = h->d_light = h->d_light_geom = nullptr;
     h->d_mat_type = nullptr;
+    h->integrator = PT_INTEGRATOR_PATH;
     h->n_prims = h->n_mats = h->n_lights = 0;
     h->scene_ready = false;
     memset(&h->bvh, 0, sizeof h->bvh);
@@ -154,7 +156,8 @@ static void free_scene(pt_context *h)
     if (h->d_mat) (void)hipFree(h->d_mat);
     if (h->d_light) (void)hipFree(h->d_light);
     if (h->d_mat_type) (void)hipFree(h->d_mat_type);
-    h->d_sph = h->d_aux = h->d_mat = h->d_light = nullptr;
+    if (h->d_light_geom) (void)hipFree(h->d_light_geom);
+    h->d_sph = h->d_aux = h->d_mat = h->d_light = h->d_light_geom = nullptr;
     h->d_mat_type = nullptr;
     if (h->d_bvh) (void)hipFree(h->d_bvh);
     h->d_bvh = nullptr;
@@ -252,6 +255,10 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
             return fail(h, PT_ERR_INVALID, "pt_init_scene: sphere %u references light %d of %u", i,
                         spheres[i].light_id, n_lights);
     }
+    for (uint32_t i = 0; i < n_lights; ++i)
+        if (lights[i].type == PT_AREA_LIGHT && lights[i].u.prim_id >= n_spheres)
+            return fail(h, PT_ERR_INVALID, "pt_init_scene: light %u sits on sphere %u of %u", i, lights[i].u.prim_id,
+                        n_spheres);
     PT_HIP(h, hipStreamSynchronize(h->stream));
     free_scene(h);
 
@@ -274,14 +281,25 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
                              materials[i].coef);
         mtype[i] = materials[i].type;
     }
-    for (uint32_t i = 0; i < n_lights; ++i)
+    std::vector<float4> light_geom(n_lights ? n_lights : 1);
+    for (uint32_t i = 0; i < n_lights; ++i) {
         light[i] = make_float4(lights[i].intensity[0], lights[i].intensity[1], lights[i].intensity[2], 0.f);
+        // what SampleLight reads (scene.h:150-170): the position, or the sphere the light sits on
+        const int32_t type = lights[i].type;
+        float tbits, pbits;
+        memcpy(&tbits, &type, 4);
+        memcpy(&pbits, &lights[i].u.prim_id, 4);
+        light_geom[i] = type == PT_AREA_LIGHT ? make_float4(pbits, 0.f, 0.f, tbits)
+                                              : make_float4(lights[i].u.pos[0], lights[i].u.pos[1], lights[i].u.pos[2], tbits);
+    }
 
     PT_HIP(h, hipMalloc((void **)&h->d_sph, sph.size() * sizeof(float4)));
     PT_HIP(h, hipMalloc((void **)&h->d_aux, aux.size() * sizeof(float4)));
     PT_HIP(h, hipMalloc((void **)&h->d_mat, mat.size() * sizeof(float4)));
     PT_HIP(h, hipMalloc((void **)&h->d_light, light.size() * sizeof(float4)));
     PT_HIP(h, hipMalloc((void **)&h->d_mat_type, mtype.size() * sizeof(int)));
+    PT_HIP(h, hipMalloc((void **)&h->d_light_geom, light_geom.size() * sizeof(float4)));
+    PT_HIP(h, hipMemcpy(h->d_light_geom, light_geom.data(), light_geom.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(h, hipMemcpy(h->d_sph, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(h, hipMemcpy(h->d_aux, aux.data(), aux.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(h, hipMemcpy(h->d_mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
@@ -339,6 +357,15 @@ int pt_set_row_bands(pt_handle h, uint32_t band_rows, uint32_t rank, uint32_t wo
     h->band_rows = world > 1 ? band_rows : 0;
     h->band_rank = rank;
     h->band_world = world;
+    return PT_OK;
+}
+
+int pt_set_integrator(pt_handle h, int integrator)
+{
+    if (!h) return PT_ERR_INVALID;
+    if (integrator != PT_INTEGRATOR_PATH && integrator != PT_INTEGRATOR_NEE_MIS)
+        return fail(h, PT_ERR_INVALID, "pt_set_integrator: unknown integrator %d", integrator);
+    h->integrator = integrator;
     return PT_OK;
 }
 
@@ -410,6 +437,7 @@ static void fill_camera(const pt_context *h, CameraParams &c)
 static void fill_scene(const pt_context *h, SceneParams &s)
 {
     s.sph = h->d_sph; s.aux = h->d_aux; s.mat = h->d_mat; s.mat_type = h->d_mat_type; s.light = h->d_light;
+    s.light_geom = h->d_light_geom;
     s.n_prims = h->n_prims; s.n_mats = h->n_mats; s.n_lights = h->n_lights;
     if (h->accel == PT_ACCEL_AUTO) s.bvh = h->bvh;
     else memset(&s.bvh, 0, sizeof s.bvh);
@@ -510,6 +538,8 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
     if (!dbuf) return fail(h, PT_ERR_INVALID, "render: buffer is NULL");
     if (n_iterations == 0) return PT_OK;
     if (h->iteration > 0xffffffffu - n_iterations) return fail(h, PT_ERR_INVALID, "iteration counter overflow");
+    if (h->wavefront && h->integrator != PT_INTEGRATOR_PATH)
+        return fail(h, PT_ERR_STATE, "the wavefront variant only implements PT_INTEGRATOR_PATH");
     if (h->wavefront) return enqueue_wavefront(h, dbuf, n_iterations);
 
     RenderParams p;
@@ -535,7 +565,10 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
     const bool tiled = p.scene.n_prims > kMaxResidentSpheres;
     if (grid_y > 0) {
         PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
-        PT_HIP(h, launch_render(p, div_up(p.cam.width, 16), grid_y, tiled, false, h->stream));
+        if (h->integrator == PT_INTEGRATOR_NEE_MIS)
+            PT_HIP(h, launch_render_nee(p, div_up(p.cam.width, 16), grid_y, tiled, false, h->stream));
+        else
+            PT_HIP(h, launch_render(p, div_up(p.cam.width, 16), grid_y, tiled, false, h->stream));
         PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
         h->timed = true;
     }
@@ -719,7 +752,10 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
         p.ray_counter = d_cnt;
         p.hit_ids = d_hits; p.path_rad = d_rad; p.pixel_rgb = d_rgb;
         const bool tiled = p.scene.n_prims > kMaxResidentSpheres;
-        DBG_HIP(launch_render(p, div_up(x1 - x0, 16), p.band_rows / 16, tiled, true, h->stream));
+        if (h->integrator == PT_INTEGRATOR_NEE_MIS)
+            DBG_HIP(launch_render_nee(p, div_up(x1 - x0, 16), p.band_rows / 16, tiled, true, h->stream));
+        else
+            DBG_HIP(launch_render(p, div_up(x1 - x0, 16), p.band_rows / 16, tiled, true, h->stream));
     }
     if (hit_ids) DBG_HIP(hipMemcpyAsync(hit_ids, d_hits, hit_elems * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     if (radiance) DBG_HIP(hipMemcpyAsync(radiance, d_rad, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));

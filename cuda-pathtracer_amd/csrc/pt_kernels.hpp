@@ -44,6 +44,7 @@ struct SceneParams {
     const float4 *mat;   // (r, g, b, coef)
     const int *mat_type; // material.h:25
     const float4 *light; // (r, g, b, -) intensity
+    const float4 *light_geom; // point light: (x, y, z, bits 0); area light: (bits sphere index, -, -, bits 1)
     uint32_t n_prims, n_mats, n_lights;
 };
 
@@ -78,6 +79,10 @@ inline size_t bvh_stack_lds_bytes(const BvhParams &b) { return (size_t)(b.depth 
 // grid_x x grid_y workgroups of 256 threads, each a 16x16 pixel tile.
 hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled,
                          bool record, hipStream_t stream);
+
+// The opt-in NEE + MIS integrator (pt_nee.hip); same launch geometry.
+hipError_t launch_render_nee(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled, bool record,
+                             hipStream_t stream);
 
 // ---- wavefront (path-compaction) variant ------------------------------------------------------
 // A batch holds n_iterations x width x height x 4 paths.  Every bounce is one kernel launch over

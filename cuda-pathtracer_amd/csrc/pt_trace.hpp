@@ -318,9 +318,9 @@ PT_DEV void intersect_bvh(const BvhParams &B, const float4 *sph, uint32_t n_prim
 // the scan, wave-wide cooperation in the BVH search); `active` masks the lanes that carry a ray.
 template <bool TILED, bool BVH = false>
 PT_DEV void intersect_scene(const SceneParams &p, const SceneView &sc, unsigned char *lds_raw, int tid,
-                            bool active, V3 o, V3 d, float &tmax, int &best)
+                            bool active, V3 o, V3 d, float &tmax, int &best, float tmax0 = PT_INF)
 {
-    tmax = PT_INF;
+    tmax = tmax0;   // upper bound of the search (tmax of scene.h:72); a hit must be strictly closer
     best = -1;
     if (BVH) {
         intersect_bvh(p.bvh, p.sph, p.n_prims, reinterpret_cast<uint2 *>(lds_raw), tid, active, o, d, tmax, best);

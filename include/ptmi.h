@@ -151,6 +151,19 @@ int pt_reset_counters(pt_handle h);
  *     (allocates about 4 GiB of queues on first use; no row bands) */
 enum { PT_VARIANT_REGENERATION = 0, PT_VARIANT_CLASSIC = 1, PT_VARIANT_WAVEFRONT = 100 };
 int pt_set_kernel_variant(pt_handle h, int variant);
+/* Integrator.
+ *   PT_INTEGRATOR_PATH (default): Trace as the reference runs it, pathtracer.cu:112-170.
+ *   PT_INTEGRATOR_NEE_MIS: adds direct-light sampling with multiple importance sampling, wiring
+ *     the functions the reference carries but never calls -- SampleLight scene.h:150-170,
+ *     Pdf scene.h:110-144, Primitive::Sample primitive.h:50-72, PowerHeuristic
+ *     montecarlo.h:156-159 -- and the commented-out `bounces == 0 || specularBounce` logic of
+ *     pathtracer.cu:117,133,148.  Three of those functions are repaired (primitive.h:67,
+ *     scene.h:117-121, scene.h:167) and area-light occlusion is decided by the nearest hit
+ *     instead of VisibilityTester's shortened segment; same expectation as PATH, lower variance
+ *     where the light is small.  pt_ray_count then includes the shadow rays.  Megakernel
+ *     variants only. */
+enum { PT_INTEGRATOR_PATH = 0, PT_INTEGRATOR_NEE_MIS = 1 };
+int pt_set_integrator(pt_handle h, int integrator);
 /* Nearest-hit search of scenes with more than 512 spheres; results are bit-identical.
  *   PT_ACCEL_AUTO (default): sphere BVH built by pt_init_scene -- the acceleration structure
  *     the reference leaves as "TODO kd-tree" (scene.h:33) -- when the scene allows one

@@ -121,5 +121,57 @@ def main():
     print("cameras.npz, camera_moves.npz written")
 
 
+def nee_inputs(rng, n, sph):
+    """Seeded inputs of the 13 direct-light sampling functions (rows of <= 16 floats)."""
+    def unit(k):
+        v = rng.normal(size=(k, 3))
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+    col = lambda a: np.asarray(a, np.float64).reshape(n, -1)
+    pos = rng.normal(size=(n, 3)) * 50
+    rad = rng.random((n, 1)) * 20 + 0.1
+    # points inside, on, just outside and far outside the sphere
+    pfrom = pos + unit(n) * rad * rng.choice([0.5, 1.0, 1.00001, 1.5, 3.0, 30.0], (n, 1))
+    room = np.column_stack([rng.uniform(-49, 49, n), rng.uniform(1, 79, n), rng.uniform(-79, 79, n)])
+    room[:n // 10] = sph["pos"][8] + unit(n // 10) * 500.0 * rng.choice([0.9, 1.0, 1.0000001], (n // 10, 1))
+    ins = {
+        "SAMPLE_SPHERE": rng.random((n, 2)),
+        "SAMPLE_CONE": np.hstack([rng.random((n, 3)), unit(n), unit(n), unit(n)]),
+        "CONE_PDF": rng.random((n, 1)),
+        "POWER_HEURISTIC": np.hstack([col(rng.integers(1, 4, n)), rng.random((n, 1)) * 5,
+                                      col(rng.integers(1, 4, n)), rng.random((n, 1)) * 5]),
+        "COORD_SYSTEM": unit(n),
+        "MATERIAL": np.hstack([col(rng.integers(0, 3, n)), rng.random((n, 3)), unit(n), unit(n), unit(n)]),
+        "LIGHT_L": np.hstack([rng.random((n, 3)) * 10, unit(n), unit(n)]),
+        "SEGMENT": np.hstack([rng.normal(size=(n, 3)) * 50, np.full((n, 1), 3e-2), rng.normal(size=(n, 3)) * 50,
+                              col(rng.choice([0, 3e-2], n))]),
+        "SPHERE_SAMPLE_AREA": np.hstack([pos, rad, rng.random((n, 2))]),
+        "SPHERE_SAMPLE_FROM": np.hstack([pos, rad, pfrom, rng.random((n, 2))]),
+        "LIGHT_PDF": np.hstack([np.full((n, 1), 8), room, unit(n)]),
+        "INTERSECT_P": np.hstack([room, unit(n), np.full((n, 1), 3e-2), rng.random((n, 1)) * 200]),
+        "SAMPLE_LIGHT": np.hstack([col(rng.integers(0, 2, n)), room, rng.random((n, 2))]),
+    }
+    return {k: v.astype(np.float32) for k, v in ins.items()}
+
+
+def nee_components():
+    """The reference's direct-light sampling functions (never called by its Trace), evaluated by the
+    reference's own host build: pins the oracle's `as_written` restatement of them."""
+    mats, sph, lights, _ = pt.build_scene(pt.SCENE_DEMO)
+    # a second light, of the point kind, so that both branches of SampleLight are covered
+    lights = np.concatenate([lights, np.zeros(1, lights.dtype)])
+    lights["type"][1] = 0
+    lights["u_bits"][1] = np.array([10.0, 60.0, -30.0], np.float32).view(np.uint32)
+    lights["intensity"][1] = [400.0, 300.0, 200.0]
+    rng = np.random.default_rng(20261111)
+    out = {"materials": mats, "spheres": sph, "lights": lights}
+    for op, x in nee_inputs(rng, 512, sph).items():
+        out["in_" + op] = x
+        out["ref_" + op] = O.ref_nee_eval(op, x, (mats, sph, lights))
+    path = os.path.join(GOLDEN, "nee_components.npz")
+    np.savez_compressed(path, **out)
+    print(f"nee_components: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
     main()
+    nee_components()

@@ -99,10 +99,16 @@ def _outputs(width, height, rect, n_iterations, max_bounces, buffer, want_paths)
     return buffer, hits, rad
 
 
+INTEGRATOR_PATH, INTEGRATOR_NEE_MIS = 0, 1
+
+
 def oracle_render(cam_pod, mats, prims, lights, seed, max_bounces, first_iteration=1, n_iterations=1,
-                  rect=None, accum_mode=ACCUM_RUNNING_MEAN, buffer=None, want_paths=False, n_threads=1):
+                  rect=None, accum_mode=ACCUM_RUNNING_MEAN, buffer=None, want_paths=False, n_threads=1,
+                  integrator=INTEGRATOR_PATH):
     """Returns (buffer[h,w,3], hit_ids or None, path_radiance or None, ray_count)."""
     lib = load_oracle()
+    lib.ptor_render_with.restype = _i32
+    lib.ptor_render_with.argtypes = [_i32] + list(lib.ptor_render.argtypes)
     cam_pod = np.ascontiguousarray(cam_pod, CAMERA_DTYPE)
     width, height = int(cam_pod["width"].reshape(-1)[0]), int(cam_pod["height"].reshape(-1)[0])
     rect = rect or (0, 0, width, height)
@@ -111,9 +117,10 @@ def oracle_render(cam_pod, mats, prims, lights, seed, max_bounces, first_iterati
     lights = np.ascontiguousarray(lights, LIGHT_DTYPE)
     buffer, hits, rad = _outputs(width, height, rect, n_iterations, max_bounces, buffer, want_paths)
     cnt = _u64(0)
-    rc = lib.ptor_render(_ptr(cam_pod), _ptr(mats), len(mats), _ptr(prims), len(prims), _ptr(lights),
-                         len(lights), seed, max_bounces, first_iteration, n_iterations, *rect,
-                         accum_mode, _ptr(buffer), _ptr(hits), _ptr(rad), ctypes.byref(cnt), n_threads)
+    rc = lib.ptor_render_with(integrator, _ptr(cam_pod), _ptr(mats), len(mats), _ptr(prims), len(prims),
+                              _ptr(lights), len(lights), seed, max_bounces, first_iteration, n_iterations,
+                              *rect, accum_mode, _ptr(buffer), _ptr(hits), _ptr(rad), ctypes.byref(cnt),
+                              n_threads)
     if rc != 0:
         raise ValueError("ptor_render: invalid arguments")
     return buffer, hits, rad, int(cnt.value)
@@ -175,3 +182,45 @@ def ref_camera_moves(eye, look_at, up, width, height, fov, ops):
     pods = np.zeros(len(o) + 1, CAMERA_DTYPE)
     lib.ref_camera_moves(_ptr(e), _ptr(l), _ptr(u), width, height, fov, _ptr(o), len(o), _ptr(pods))
     return pods
+
+
+# ---- direct-light sampling components (the reference's dormant code) -------------------------------
+NEE_OPS = {name: i for i, name in enumerate([
+    "SAMPLE_SPHERE", "SAMPLE_CONE", "CONE_PDF", "POWER_HEURISTIC", "COORD_SYSTEM", "MATERIAL", "LIGHT_L",
+    "SEGMENT", "SPHERE_SAMPLE_AREA", "SPHERE_SAMPLE_FROM", "LIGHT_PDF", "INTERSECT_P", "SAMPLE_LIGHT"])}
+
+
+def _nee_args(op, inputs, scene):
+    x = np.zeros((len(inputs), 16), np.float32)
+    a = np.asarray(inputs, np.float32)
+    x[:, :a.shape[1]] = a
+    mats, prims, lights = scene if scene is not None else (np.zeros(0, MATERIAL_DTYPE), np.zeros(0, SPHERE_DTYPE),
+                                                           np.zeros(0, LIGHT_DTYPE))
+    mats = np.ascontiguousarray(mats, MATERIAL_DTYPE)
+    prims = np.ascontiguousarray(prims, SPHERE_DTYPE)
+    lights = np.ascontiguousarray(lights, LIGHT_DTYPE)
+    return NEE_OPS[op] if isinstance(op, str) else int(op), x, mats, prims, lights, np.zeros((len(x), 16), np.float32)
+
+
+def nee_eval(op, inputs, scene=None, as_written=False):
+    """Oracle: rows of `inputs` through one of the direct-light sampling functions -> [n,16]."""
+    lib = load_oracle()
+    lib.ptor_nee_eval.restype = _i32
+    lib.ptor_nee_eval.argtypes = [_i32, _i32, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _vp, _u32]
+    op, x, mats, prims, lights, out = _nee_args(op, inputs, scene)
+    if lib.ptor_nee_eval(op, int(as_written), _ptr(mats), len(mats), _ptr(prims), len(prims), _ptr(lights),
+                         len(lights), _ptr(x), _ptr(out), len(x)) != 0:
+        raise ValueError("ptor_nee_eval: invalid arguments")
+    return out
+
+
+def ref_nee_eval(op, inputs, scene=None):
+    """The reference's own functions (host build, deterministic sin/cos injected) -> [n,16]."""
+    lib = load_ref()
+    lib.ref_nee_eval.restype = _i32
+    lib.ref_nee_eval.argtypes = [_i32, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _vp, _u32]
+    op, x, mats, prims, lights, out = _nee_args(op, inputs, scene)
+    if lib.ref_nee_eval(op, _ptr(mats), len(mats), _ptr(prims), len(prims), _ptr(lights), len(lights),
+                        _ptr(x), _ptr(out), len(x)) != 0:
+        raise ValueError("ref_nee_eval: invalid arguments")
+    return out

@@ -51,6 +51,7 @@ typedef struct {
     uint32_t n_mats, n_prims, n_lights;
     uint64_t seed;
     int max_bounces;
+    int integrator;
 } scene_ctx;
 
 typedef struct {
@@ -260,6 +261,8 @@ static v3 trace(const scene_ctx *sc, v3 o, v3 d, uint32_t pixel, uint32_t iterat
     return L;
 }
 
+#include "pt_oracle_nee.h"
+
 void ptor_camera_init(ptor_camera *out, const float eye[3], const float look_at[3],
                       const float up_[3], uint32_t width, uint32_t height, float fov)
 {
@@ -417,7 +420,9 @@ static void render_pixel(job_t *job, uint32_t x, uint32_t y, uint32_t it_idx)
         float sy = ((float)(int)y + s[i * 2 + 1]);
         v3 dir = v3_normalize(v3_add(v3_sub(first, v3_scale(pxY, sy)), v3_scale(pxX, sx)));
         int32_t *hits = job->hit_ids ? job->hit_ids + (rp * 4 + i) * (size_t)(mb + 1) : NULL;
-        v3 Lp = trace(sc, v3_load(cam->pos), dir, index, iteration, hits, &job->n_rays);
+        v3 Lp = sc->integrator == PTOR_INTEGRATOR_NEE_MIS
+                    ? trace_nee(sc, v3_load(cam->pos), dir, index, iteration, hits, &job->n_rays)
+                    : trace(sc, v3_load(cam->pos), dir, index, iteration, hits, &job->n_rays);
         if (job->path_radiance) {
             float *pr = job->path_radiance + (rp * 4 + i) * 3;
             pr[0] = Lp.x; pr[1] = Lp.y; pr[2] = Lp.z;
@@ -458,6 +463,25 @@ int ptor_render(const ptor_camera *cam,
                 int32_t *hit_ids, float *path_radiance, uint64_t *ray_count,
                 int n_threads)
 {
+    return ptor_render_with(PTOR_INTEGRATOR_PATH, cam, mats, n_mats, prims, n_prims, lights, n_lights, seed,
+                            max_bounces, first_iteration, n_iterations, x0, y0, x1, y1, accum_mode, buffer,
+                            hit_ids, path_radiance, ray_count, n_threads);
+}
+
+int ptor_render_with(int integrator, const ptor_camera *cam,
+                     const ptor_material *mats, uint32_t n_mats,
+                     const ptor_sphere *prims, uint32_t n_prims,
+                     const ptor_light *lights, uint32_t n_lights,
+                     uint64_t seed, int max_bounces,
+                     uint32_t first_iteration, uint32_t n_iterations,
+                     uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                     int accum_mode, float *buffer,
+                     int32_t *hit_ids, float *path_radiance, uint64_t *ray_count,
+                     int n_threads)
+{
+    if (integrator != PTOR_INTEGRATOR_PATH && integrator != PTOR_INTEGRATOR_NEE_MIS) return -1;
+    for (uint32_t i = 0; i < n_lights; ++i)
+        if (lights && lights[i].type == 1 && lights[i].u.prim_id >= n_prims) return -1;
     if (!cam || !buffer || max_bounces < 0 || first_iteration == 0) return -1;
     if (x1 > cam->width || y1 > cam->height || x0 > x1 || y0 > y1) return -1;
     if ((n_prims && !prims) || (n_mats && !mats) || (n_lights && !lights)) return -1;
@@ -465,7 +489,7 @@ int ptor_render(const ptor_camera *cam,
         if (prims[i].material_id >= n_mats) return -1;
         if (prims[i].light_id >= (int32_t)n_lights) return -1;
     }
-    scene_ctx sc = { cam, mats, prims, lights, n_mats, n_prims, n_lights, seed, max_bounces };
+    scene_ctx sc = { cam, mats, prims, lights, n_mats, n_prims, n_lights, seed, max_bounces, integrator };
 
     uint32_t rows = y1 - y0;
     if (n_threads < 1) n_threads = 1;

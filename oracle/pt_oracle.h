@@ -107,6 +107,48 @@ int ptor_render(const ptor_camera *cam,
                 int32_t *hit_ids, float *path_radiance, uint64_t *ray_count,
                 int n_threads);
 
+/* Same with a choice of integrator: PATH is Trace as the reference runs it; NEE_MIS adds the
+ * reference's dormant direct-light sampling (see pt_oracle_nee.h).  ray_count then includes the
+ * shadow rays; hit_ids still lists the nearest-hit calls only. */
+enum { PTOR_INTEGRATOR_PATH = 0, PTOR_INTEGRATOR_NEE_MIS = 1 };
+int ptor_render_with(int integrator, const ptor_camera *cam,
+                     const ptor_material *mats, uint32_t n_mats,
+                     const ptor_sphere *prims, uint32_t n_prims,
+                     const ptor_light *lights, uint32_t n_lights,
+                     uint64_t seed, int max_bounces,
+                     uint32_t first_iteration, uint32_t n_iterations,
+                     uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                     int accum_mode, float *buffer,
+                     int32_t *hit_ids, float *path_radiance, uint64_t *ray_count,
+                     int n_threads);
+
+/* The direct-light sampling functions one by one, for the pin tests: `count` items of 16 floats
+ * in, 16 floats out (unused slots 0).  as_written selects the reference's text, bugs included,
+ * where a repaired form exists (see pt_oracle_nee.h).  Ops 10-12 need the scene.
+ *   op                         in                                   out
+ *   SAMPLE_SPHERE              u1 u2                                dir(3)
+ *   SAMPLE_CONE                u1 u2 cosThetaMax x(3) y(3) z(3)     dir(3)
+ *   CONE_PDF                   cosThetaMax                          pdf
+ *   POWER_HEURISTIC            nf fPdf ng gPdf                      weight
+ *   COORD_SYSTEM               v1(3)                                v2(3) v3(3)
+ *   MATERIAL                   type color(3) wo(3) wi(3) n(3)       F(3) Pdf
+ *   LIGHT_L                    intensity(3) w(3) n(3)               L(3)
+ *   SEGMENT                    p1(3) eps1 p2(3) eps2                o(3) d(3) mint maxt
+ *   SPHERE_SAMPLE_AREA         pos(3) radius u v                    p(3) ns(3)
+ *   SPHERE_SAMPLE_FROM         pos(3) radius p(3) u v               ps(3) ns(3)
+ *   LIGHT_PDF                  prim p(3) wi(3)                      pdf
+ *   INTERSECT_P                o(3) d(3) tmin tmax                  0 / 1
+ *   SAMPLE_LIGHT               light p(3) u v                       Li(3) wi(3) pdf o(3) d(3) mint maxt */
+enum {
+    PTOR_NEE_SAMPLE_SPHERE = 0, PTOR_NEE_SAMPLE_CONE, PTOR_NEE_CONE_PDF, PTOR_NEE_POWER_HEURISTIC,
+    PTOR_NEE_COORD_SYSTEM, PTOR_NEE_MATERIAL, PTOR_NEE_LIGHT_L, PTOR_NEE_SEGMENT,
+    PTOR_NEE_SPHERE_SAMPLE_AREA, PTOR_NEE_SPHERE_SAMPLE_FROM, PTOR_NEE_LIGHT_PDF, PTOR_NEE_INTERSECT_P,
+    PTOR_NEE_SAMPLE_LIGHT
+};
+int ptor_nee_eval(int op, int as_written,
+                  const ptor_material *mats, uint32_t n_mats, const ptor_sphere *prims, uint32_t n_prims,
+                  const ptor_light *lights, uint32_t n_lights, const float *in, float *out, uint32_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@
 
 #define PTOR_STREAM_CAMERA 0u
 #define PTOR_STREAM_PATH   1u
+#define PTOR_STREAM_LIGHT  2u   /* direct-light sampling: slot = bounce -> (u, v, light choice, -) */
 
 /* Philox4x32-10: multipliers and Weyl key increments from the Random123 paper. */
 static inline void ptor_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])

@@ -238,4 +238,104 @@ int ref_render(const float eye[3], const float look_at[3], const float up[3],
     return 0;
 }
 
+/* The reference's direct-light sampling functions, which Trace never calls, evaluated one by one
+ * exactly as written (same contract as ptor_nee_eval with as_written = 1). */
+int ref_nee_eval(int op, const ptor_material *mats, uint32_t n_mats, const ptor_sphere *prims, uint32_t n_prims,
+                 const ptor_light *lights, uint32_t n_lights, const float *in_all, float *out_all, uint32_t count)
+{
+    std::vector<Material> mv;
+    for (uint32_t i = 0; i < n_mats; ++i) {
+        Color c(mats[i].color[0], mats[i].color[1], mats[i].color[2]);
+        if (mats[i].type == 0) mv.push_back(CreateDiffuseMaterial(c, mats[i].coef));
+        else if (mats[i].type == 1) mv.push_back(CreateSpecularMaterial(c, mats[i].coef));
+        else mv.push_back(CreateTransmissiveMaterial(c, mats[i].coef));
+    }
+    std::vector<Primitive> pv;
+    for (uint32_t i = 0; i < n_prims; ++i)
+        pv.push_back(Primitive(Point(prims[i].pos[0], prims[i].pos[1], prims[i].pos[2]),
+                               prims[i].radius, prims[i].material_id, prims[i].light_id));
+    Light *lv = (Light *)malloc(sizeof(Light) * (n_lights ? n_lights : 1));
+    for (uint32_t i = 0; i < n_lights; ++i) {
+        Color c(lights[i].intensity[0], lights[i].intensity[1], lights[i].intensity[2]);
+        if (lights[i].type == 1) new (&lv[i]) Light(lights[i].u.prim_id, c);
+        else new (&lv[i]) Light(Point(lights[i].u.pos[0], lights[i].u.pos[1], lights[i].u.pos[2]), c);
+    }
+    Scene scene(MaterialList(mv.data(), (uint32_t)mv.size()),
+                PrimitiveList(pv.data(), (uint32_t)pv.size()), LightList(lv, n_lights));
+    int rc = 0;
+    for (uint32_t i = 0; i < count && rc == 0; ++i) {
+        const float *in = in_all + (size_t)i * 16;
+        float *out = out_all + (size_t)i * 16;
+        for (int k = 0; k < 16; ++k) out[k] = 0.f;
+        auto put3 = [out](int at, float x, float y, float z) { out[at] = x; out[at + 1] = y; out[at + 2] = z; };
+        switch (op) {
+        case PTOR_NEE_SAMPLE_SPHERE: { Vec v = UniformSampleSphere(in[0], in[1]); put3(0, v.x, v.y, v.z); break; }
+        case PTOR_NEE_SAMPLE_CONE: {
+            Vec v = UniformSampleCone(in[0], in[1], in[2], Vec(in[3], in[4], in[5]), Vec(in[6], in[7], in[8]),
+                                      Vec(in[9], in[10], in[11]));
+            put3(0, v.x, v.y, v.z); break;
+        }
+        case PTOR_NEE_CONE_PDF: out[0] = UniformConePdf(in[0]); break;
+        case PTOR_NEE_POWER_HEURISTIC: out[0] = PowerHeuristic((int)in[0], in[1], (int)in[2], in[3]); break;
+        case PTOR_NEE_COORD_SYSTEM: {
+            Vec v2, v3;
+            CoordinateSystem(Vec(in[0], in[1], in[2]), &v2, &v3);
+            put3(0, v2.x, v2.y, v2.z); put3(3, v3.x, v3.y, v3.z); break;
+        }
+        case PTOR_NEE_MATERIAL: {
+            Material m;
+            m.type = (MaterialType)(int)in[0]; m.color = Color(in[1], in[2], in[3]); m.coef = 0.f;
+            const Vec wo(in[4], in[5], in[6]), wi(in[7], in[8], in[9]), n(in[10], in[11], in[12]);
+            Color f = m.F(wo, wi, n);
+            put3(0, f.r, f.g, f.b);
+            out[3] = Pdf(&m, wo, wi, n); break;
+        }
+        case PTOR_NEE_LIGHT_L: {
+            Light l(0u, Color(in[0], in[1], in[2]));
+            Color c = l.L(Point(), Vec(in[3], in[4], in[5]), Vec(in[6], in[7], in[8]));
+            put3(0, c.r, c.g, c.b); break;
+        }
+        case PTOR_NEE_SEGMENT: {
+            VisibilityTester vt;
+            vt.SetSegment(Point(in[0], in[1], in[2]), in[3], Point(in[4], in[5], in[6]), in[7]);
+            put3(0, vt.r.o.x, vt.r.o.y, vt.r.o.z); put3(3, vt.r.d.x, vt.r.d.y, vt.r.d.z);
+            out[6] = vt.mint; out[7] = vt.maxt; break;
+        }
+        case PTOR_NEE_SPHERE_SAMPLE_AREA: {
+            Primitive prim(Point(in[0], in[1], in[2]), in[3], 0);
+            Vec ns;
+            Point p = prim.Sample(UVSample(in[4], in[5]), &ns);
+            put3(0, p.x, p.y, p.z); put3(3, ns.x, ns.y, ns.z); break;
+        }
+        case PTOR_NEE_SPHERE_SAMPLE_FROM: {
+            Primitive prim(Point(in[0], in[1], in[2]), in[3], 0);
+            Vec ns;
+            Point p = prim.Sample(Point(in[4], in[5], in[6]), UVSample(in[7], in[8]), &ns);
+            put3(0, p.x, p.y, p.z); put3(3, ns.x, ns.y, ns.z); break;
+        }
+        case PTOR_NEE_LIGHT_PDF:
+            if ((uint32_t)in[0] >= n_prims) { rc = -1; break; }
+            out[0] = Pdf(&scene, scene.primitives[(uint32_t)in[0]], Point(in[1], in[2], in[3]), Vec(in[4], in[5], in[6]));
+            break;
+        case PTOR_NEE_INTERSECT_P:
+            out[0] = IntersectP(&scene, Ray(Point(in[0], in[1], in[2]), Vec(in[3], in[4], in[5])), in[6], in[7]) ? 1.f : 0.f;
+            break;
+        case PTOR_NEE_SAMPLE_LIGHT: {
+            if ((uint32_t)in[0] >= n_lights) { rc = -1; break; }
+            Vec wi;
+            float pdf = 0.f;
+            VisibilityTester vt;
+            Color li = SampleLight(scene.lights[(uint32_t)in[0]], Point(in[1], in[2], in[3]), &wi, &pdf, &vt,
+                                   UVSample(in[4], in[5]), &scene);
+            put3(0, li.r, li.g, li.b); put3(3, wi.x, wi.y, wi.z); out[6] = pdf;
+            put3(7, vt.r.o.x, vt.r.o.y, vt.r.o.z); put3(10, vt.r.d.x, vt.r.d.y, vt.r.d.z);
+            out[13] = vt.mint; out[14] = vt.maxt; break;
+        }
+        default: rc = -1; break;
+        }
+    }
+    free(lv);
+    return rc;
+}
+
 } /* extern "C" */
