@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 regeneration, 1 classic)")
     ap.add_argument("--accel", default="auto", choices=["auto", "brute"],
                     help="scenes above 512 spheres: sphere BVH (auto) or the reference's linear scan (brute)")
+    ap.add_argument("--integrator", default="path", choices=["path", "nee"],
+                    help="path: the reference's Trace (the headline metric); nee: opt-in direct-light sampling "
+                         "with MIS (bounces then include the shadow rays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -152,6 +155,7 @@ def main():
     tr.Init(mats, sph, lights)
     tr.SetKernelVariant(args.variant)
     tr.SetAccel(pt.ACCEL_AUTO if args.accel == "auto" else pt.ACCEL_BRUTE_FORCE)
+    tr.SetIntegrator(pt.INTEGRATOR_NEE_MIS if args.integrator == "nee" else pt.INTEGRATOR_PATH)
     bvh = args.accel == "auto" and tr.AccelNodes() > 0
     tr.SetStream(torch.cuda.current_stream().cuda_stream)
     if world > 1:
@@ -235,14 +239,14 @@ def main():
                        "bounces_per_step_per_gpu": rays_per_launch, "spheres": int(len(sph)),
                        "parallelism": "single" if world == 1 else f"sample-range split x{world} + RCCL reduce(sum)",
                        "kernel_variant": args.variant,
-                       "nearest_hit": "sphere BVH" if bvh else "linear scan"},
+                       "nearest_hit": "sphere BVH" if bvh else "linear scan", "integrator": args.integrator},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS if achieved else None,
                          "traffic": traffic,
                          "kernel": "render_kernel", "launch_ms": launch_ms,
                          "flops_per_bounce": fpr, "bounces_per_launch": rays_per_launch},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.integrator == "path":
             def gpu_render(n):
                 tr.Reset()
                 tr.RunN(buf, n, sync=True)

@@ -3,7 +3,7 @@
 // change can be checked for speed and for bit-identical output in one short GPU call.
 //   pt_bench <scene 0|1|2> <width> <height> <iterations> <depth> <repeats> [variants]
 // variants: comma-separated pt_set_kernel_variant values; +1000 selects the brute-force scan
-// (PT_ACCEL_BRUTE_FORCE) for that entry.
+// (PT_ACCEL_BRUTE_FORCE), +2000 the NEE + MIS integrator for that entry.
 #include "ptmi.h"
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -42,7 +42,8 @@ int main(int argc, char **argv)
     std::vector<float> img(n);
     for (int r = 0; r < repeats * (int)variants.size(); ++r) {
         const int variant = variants[r % variants.size()];
-        pt_set_accel(hd, variant >= 1000 ? PT_ACCEL_BRUTE_FORCE : PT_ACCEL_AUTO);
+        pt_set_accel(hd, variant % 2000 >= 1000 ? PT_ACCEL_BRUTE_FORCE : PT_ACCEL_AUTO);
+        pt_set_integrator(hd, variant >= 2000 ? PT_INTEGRATOR_NEE_MIS : PT_INTEGRATOR_PATH);
         if (pt_set_kernel_variant(hd, variant % 1000) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
         pt_reset(hd); pt_reset_counters(hd);
         const auto t0 = std::chrono::steady_clock::now();
