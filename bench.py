@@ -115,7 +115,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="demo1080", choices=sorted(WORKLOADS))
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 regeneration, 1 classic)")
+    ap.add_argument("--variant", type=int, default=-1,
+                    help="kernel variant (-1 auto: wavefront for BVH scenes, else 0; 0 regeneration megakernel, "
+                         "1 classic megakernel, 100 wavefront)")
     ap.add_argument("--accel", default="auto", choices=["auto", "brute"],
                     help="scenes above 512 spheres: sphere BVH (auto) or the reference's linear scan (brute)")
     ap.add_argument("--integrator", default="path", choices=["path", "nee"],
@@ -157,6 +159,8 @@ def main():
     tr.SetAccel(pt.ACCEL_AUTO if args.accel == "auto" else pt.ACCEL_BRUTE_FORCE)
     tr.SetIntegrator(pt.INTEGRATOR_NEE_MIS if args.integrator == "nee" else pt.INTEGRATOR_PATH)
     bvh = args.accel == "auto" and tr.AccelNodes() > 0
+    # what PT_VARIANT_AUTO resolves to (pt_set_kernel_variant in include/ptmi.h)
+    eff_variant = args.variant if args.variant >= 0 else (100 if bvh and args.integrator == "path" else 0)
     tr.SetStream(torch.cuda.current_stream().cuda_stream)
     if world > 1:
         tr.SetAccumMode(pt.ACCUM_SUM)
@@ -217,7 +221,7 @@ def main():
     # HBM bytes per step from the committed PMC passes of this same command (rocprofv3 cannot be
     # run from inside the benchmark): profiles/pmc_traffic_<workload>_v<variant>.json
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}{'_bvh' if bvh else ''}_v{args.variant}.json")
+    tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}{'_bvh' if bvh else ''}_v{eff_variant}.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f).get("hbm_bytes_per_step")
@@ -238,12 +242,13 @@ def main():
             "config": {"workload": wl["label"], "paths_per_step_per_gpu": wl["width"] * wl["height"] * 4 * n_it,
                        "bounces_per_step_per_gpu": rays_per_launch, "spheres": int(len(sph)),
                        "parallelism": "single" if world == 1 else f"sample-range split x{world} + RCCL reduce(sum)",
-                       "kernel_variant": args.variant,
+                       "kernel_variant": eff_variant,
                        "nearest_hit": "sphere BVH" if bvh else "linear scan", "integrator": args.integrator},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS if achieved else None,
                          "traffic": traffic,
-                         "kernel": "render_kernel", "launch_ms": launch_ms,
+                         "kernel": "render_kernel" if eff_variant < 100 else "wf_step_* (all launches of a step)",
+                         "launch_ms": launch_ms,
                          "flops_per_bounce": fpr, "bounces_per_launch": rays_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline and args.integrator == "path":

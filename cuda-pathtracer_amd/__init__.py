@@ -39,7 +39,7 @@ POINT_LIGHT, AREA_LIGHT = 0, 1
 ACCUM_RUNNING_MEAN, ACCUM_SUM = 0, 1
 HIT_MISS, HIT_NOT_TRACED = -1, -2
 SCENE_DEMO, SCENE_SYNTH10K, SCENE_MIXED = 0, 1, 2
-VARIANT_REGENERATION, VARIANT_CLASSIC, VARIANT_WAVEFRONT = 0, 1, 100
+VARIANT_AUTO, VARIANT_REGENERATION, VARIANT_CLASSIC, VARIANT_WAVEFRONT = -1, 0, 1, 100
 ACCEL_AUTO, ACCEL_BRUTE_FORCE = 0, 1
 INTEGRATOR_PATH, INTEGRATOR_NEE_MIS = 0, 1
 PT_OK, PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_DEVICE, PT_ERR_NOMEM = 0, -1, -2, -3, -4

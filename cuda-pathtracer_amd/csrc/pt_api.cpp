@@ -47,6 +47,8 @@ struct pt_context {
     bool timed;
     // wavefront variant: queues, per-path radiance and counters, allocated on first use
     bool wavefront;
+    bool auto_variant;
+    int wf_dynamic_fetch;   // BVH scenes: refill threshold of the persistent waves, 0 = static chunks
     WavefrontQueue wf_queue[2];
     float *wf_radiance;
     uint32_t *wf_counts;
@@ -133,6 +135,8 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->ev_start = h->ev_stop = nullptr;
     h->timed = false;
     h->wavefront = false;
+    h->auto_variant = true;
+    h->wf_dynamic_fetch = 44;
     memset(h->wf_queue, 0, sizeof h->wf_queue);
     h->wf_radiance = nullptr;
     h->wf_counts = nullptr;
@@ -403,8 +407,16 @@ int pt_set_kernel_variant(pt_handle h, int variant)
 {
     if (!h) return PT_ERR_INVALID;
     h->wavefront = false;
+    h->auto_variant = false;
     h->small_scene_opts = 1;
-    if (variant == PT_VARIANT_WAVEFRONT) h->wavefront = true;
+    h->wf_dynamic_fetch = 44;
+    if (variant == PT_VARIANT_AUTO) { h->auto_variant = true; h->regen_min_idle = 1; }
+    else if (variant >= PT_VARIANT_WAVEFRONT && variant <= PT_VARIANT_WAVEFRONT + 64) {
+        // +1: static assignment of paths to lanes; +2..+64: refill threshold of the dynamic fetch (A/B)
+        h->wavefront = true;
+        const int k = variant - PT_VARIANT_WAVEFRONT;
+        h->wf_dynamic_fetch = k == 0 ? 44 : (k == 1 ? 0 : k);
+    }
     else if (variant >= 300 && variant <= 301) { h->regen_min_idle = 1; h->small_scene_opts = variant - 300; } // experiments
     else if (variant == 0) h->regen_min_idle = 1;
     else if (variant == 1) h->regen_min_idle = 64;
@@ -498,6 +510,7 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
     fill_scene(h, p.scene);
     p.seed = h->seed;
     p.max_bounces = h->max_bounces;
+    p.dynamic_fetch = h->wf_dynamic_fetch;
     p.sub_capacity = h->wf_sub_capacity;
     p.counts = h->wf_counts;
     p.path_radiance = h->wf_radiance;
@@ -541,6 +554,11 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
     if (h->wavefront && h->integrator != PT_INTEGRATOR_PATH)
         return fail(h, PT_ERR_STATE, "the wavefront variant only implements PT_INTEGRATOR_PATH");
     if (h->wavefront) return enqueue_wavefront(h, dbuf, n_iterations);
+    // PT_VARIANT_AUTO: BVH traversals differ so much in length that the queue-fed persistent waves
+    // are twice as fast as the megakernel (measured); everything else stays with the megakernel.
+    if (h->auto_variant && h->accel == PT_ACCEL_AUTO && h->bvh.n_nodes > 0 && h->band_world == 1 &&
+        h->integrator == PT_INTEGRATOR_PATH && h->iteration + (uint64_t)n_iterations < (1u << 30))
+        return enqueue_wavefront(h, dbuf, n_iterations);
 
     RenderParams p;
     fill_params(h, p);

@@ -107,9 +107,12 @@ struct WavefrontParams {
     uint32_t n_iterations;      // in the batch
     int bounce;                 // bounce index handled by this launch
     WavefrontQueue in, out;     // in is unused for bounce 0 (camera rays are generated)
+    int dynamic_fetch;          // BVH scenes: persistent waves refill when fewer lanes than this still
+                                // traverse (0: static chunks of 256 paths)
     uint32_t sub_capacity;      // paths per sub-queue, a multiple of 256
-    uint32_t *counts;           // [max_bounces + 2][kWfSubQueues][kWfCountStride]: paths alive in
-                                // sub-queue q entering bounce k
+    uint32_t *counts;           // [max_bounces + 2][kWfSubQueues][kWfCountStride]: word 0 = paths alive
+                                // in sub-queue q entering bounce k, word 1 = fetch cursor of the
+                                // dynamic-fetch kernel over those paths
     float *path_radiance;       // [paths][3]
     // resolve
     int accum_mode, overwrite;

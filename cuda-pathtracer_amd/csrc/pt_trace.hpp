@@ -201,85 +201,87 @@ PT_DEV bool bvh_pop(const uint2 *stack, int &sp, float tmax, int &cur)
 // order -- and the wave then finishes such rays together, one at a time: 64 lanes scan the sphere
 // array in stride and reduce (t, index) across the wave.  Every lane of the wave must call this
 // function (`active` masks the lanes that carry a ray).
-PT_DEV void intersect_bvh(const BvhParams &B, const float4 *sph, uint32_t n_prims, uint2 *stack, int tid,
-                          bool active, V3 o, V3 d, float &tmax, int &best)
-{
-    bool more = active;
-    float e = 0.f;
-    bool refine = false;
+constexpr int kBvhNodeStepsPerLeafStep = 3;
+
+struct BvhTraversal {
     BvhMargin m;
     BvhRay ray;
-    if (active) {
-        for (uint32_t i = 0; i < B.n_big; ++i) sphere_test_lex(B.big_sph[i], B.big_index[i], o, d, tmax, best);
-        const float cx = o.x - B.centre[0], cy = o.y - B.centre[1], cz = o.z - B.centre[2];
-        const float L = __builtin_sqrtf(cx * cx + cy * cy + cz * cz) * 1.000001f + B.half_diag;
-        const float excess = (d.x * d.x + d.y * d.y + d.z * d.z) - 1.f;
-        // a NaN in the origin or the direction makes every sphere test fail (all comparisons false)
-        if (excess != excess || L != L) more = false;
-        m.eps = __builtin_fmaxf(excess, 0.f) * 1.000001f + 4e-7f;
-        // b = op . dir grows with |dir|, and with it the rounding errors of b * b and of t = b -+ sqrt(det)
-        m.err = 1e-6f * L * L * (1.f + m.eps);
-        // slab arithmetic: plane * inv + k cancels two terms of the size of the coordinates
-        m.slack = (2e-6f * L + 4e-7f * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z))) * (1.f + m.eps);
-        m.r_min = B.r_min;
-        e = m.at(__builtin_fminf(tmax, (2.2f * (1.f + m.eps) + 0.1f) * L));
-        refine = m.eps > 2e-6f;
-        // overflow (absurdly long directions, far origins): visit everything, like the scan
-        if (!(e < 3.0e38f)) { e = PT_INF; refine = false; }
-        ray.inv = mk(bvh_inverse(d.x), bvh_inverse(d.y), bvh_inverse(d.z));
-        ray.widen(o, e);
+    float e;           // widening for hits anywhere up to the ray's initial bound
+    bool refine;       // direction noticeably longer than 1: narrow the widening per box
+    int cur, sp;       // current node reference and stack height
+    uint32_t visits;
+};
+
+// Starts a traversal: tests the always-tested spheres, derives the ray's widening and slab
+// constants.  Returns false when there is nothing to traverse (NaN in the ray).
+PT_DEV bool bvh_begin(const BvhParams &B, V3 o, V3 d, float &tmax, int &best, BvhTraversal &tr)
+{
+    for (uint32_t i = 0; i < B.n_big; ++i) sphere_test_lex(B.big_sph[i], B.big_index[i], o, d, tmax, best);
+    const float cx = o.x - B.centre[0], cy = o.y - B.centre[1], cz = o.z - B.centre[2];
+    const float L = __builtin_sqrtf(cx * cx + cy * cy + cz * cz) * 1.000001f + B.half_diag;
+    const float excess = (d.x * d.x + d.y * d.y + d.z * d.z) - 1.f;
+    tr.m.eps = __builtin_fmaxf(excess, 0.f) * 1.000001f + 4e-7f;
+    // b = op . dir grows with |dir|, and with it the rounding errors of b * b and of t = b -+ sqrt(det)
+    tr.m.err = 1e-6f * L * L * (1.f + tr.m.eps);
+    // slab arithmetic: plane * inv + k cancels two terms of the size of the coordinates
+    tr.m.slack = (2e-6f * L + 4e-7f * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z))) * (1.f + tr.m.eps);
+    tr.m.r_min = B.r_min;
+    tr.e = tr.m.at(__builtin_fminf(tmax, (2.2f * (1.f + tr.m.eps) + 0.1f) * L));
+    tr.refine = tr.m.eps > 2e-6f;
+    // overflow (absurdly long directions, far origins): visit everything, like the scan
+    if (!(tr.e < 3.0e38f)) { tr.e = PT_INF; tr.refine = false; }
+    tr.ray.inv = mk(bvh_inverse(d.x), bvh_inverse(d.y), bvh_inverse(d.z));
+    tr.ray.widen(o, tr.e);
+    tr.cur = 0; tr.sp = 0; tr.visits = 0;
+    // a NaN in the origin or the direction makes every sphere test fail (all comparisons false)
+    return !(excess != excess || L != L);
+}
+
+// One inner node (tr.cur >= 0): tests both children, descends into the nearer one.  Returns false
+// when the traversal is finished (stack empty).
+PT_DEV bool bvh_node_step(const BvhParams &B, uint2 *stack, V3 o, float tmax, BvhTraversal &tr)
+{
+    const float4 *N = B.nodes + 4 * (size_t)tr.cur;
+    const float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+    float tn0, tn1;
+    const bool hit0 = bvh_box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tr.ray, o, tr.e, tr.refine, tr.m, tmax, tn0);
+    const bool hit1 = bvh_box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr.ray, o, tr.e, tr.refine, tr.m, tmax, tn1);
+    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+    ++tr.visits;
+    if (hit0 && hit1) {
+        const bool first0 = tn0 <= tn1;
+        stack[tr.sp * kBlockThreads] = make_uint2((uint32_t)(first0 ? c1 : c0), __float_as_uint(first0 ? tn1 : tn0));
+        ++tr.sp;
+        tr.cur = first0 ? c0 : c1;
+        return true;
     }
-    stack += tid;
-    int cur = 0, sp = 0;
-    uint32_t visits = 0;
-    bool over_budget = false;
-#ifdef PT_BVH_STATS
-    uint32_t st_nodes = 0, st_leaves = 0, st_wave_nodes = 0, st_wave_leaves = 0;
-    const bool st_leader = (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1;
-#define PT_BVH_COUNT(x) (++(x))
-#define PT_BVH_WAVE_COUNT(x) do { if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) ++(x); } while (0)
-#else
-#define PT_BVH_COUNT(x) ((void)0)
-#define PT_BVH_WAVE_COUNT(x) ((void)0)
-#endif
-    while (more) {
-        while (more && cur >= 0) {
-            PT_BVH_COUNT(st_nodes);
-            PT_BVH_WAVE_COUNT(st_wave_nodes);
-            const float4 *N = B.nodes + 4 * (size_t)cur;
-            const float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
-            float tn0, tn1;
-            const bool hit0 = bvh_box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, o, e, refine, m, tmax, tn0);
-            const bool hit1 = bvh_box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, o, e, refine, m, tmax, tn1);
-            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-            if (hit0 && hit1) {
-                const bool first0 = tn0 <= tn1;
-                stack[sp * kBlockThreads] = make_uint2((uint32_t)(first0 ? c1 : c0), __float_as_uint(first0 ? tn1 : tn0));
-                ++sp;
-                cur = first0 ? c0 : c1;
-            } else if (hit0 || hit1) {
-                cur = hit0 ? c0 : c1;
-            } else {
-                more = bvh_pop(stack, sp, tmax, cur);
-            }
-            if (++visits > B.budget) { over_budget = more; more = false; }
-        }
-        if (more) {
-            PT_BVH_COUNT(st_leaves);
-            PT_BVH_WAVE_COUNT(st_wave_leaves);
-            const uint32_t leaf = (uint32_t)~cur;
-            const float4 *S = B.leaf_sph + 4 * (size_t)leaf;
-            const float4 s0 = S[0], s1 = S[1], s2 = S[2], s3 = S[3];
-            const int4 id = B.leaf_index[leaf];
-            sphere_test_lex(s0, id.x, o, d, tmax, best);
-            sphere_test_lex(s1, id.y, o, d, tmax, best);
-            sphere_test_lex(s2, id.z, o, d, tmax, best);
-            sphere_test_lex(s3, id.w, o, d, tmax, best);
-            more = bvh_pop(stack, sp, tmax, cur);
-            ++visits;
-        }
+    if (hit0 || hit1) {
+        tr.cur = hit0 ? c0 : c1;
+        return true;
     }
-    // rays over budget: the wave scans all spheres for each of them in turn
+    return bvh_pop(stack, tr.sp, tmax, tr.cur);
+}
+
+// One leaf (tr.cur < 0): its four sphere slots, then the next deferred box.
+PT_DEV bool bvh_leaf_step(const BvhParams &B, uint2 *stack, V3 o, V3 d, float &tmax, int &best, BvhTraversal &tr)
+{
+    const uint32_t leaf = (uint32_t)~tr.cur;
+    const float4 *S = B.leaf_sph + 4 * (size_t)leaf;
+    const float4 s0 = S[0], s1 = S[1], s2 = S[2], s3 = S[3];
+    const int4 id = B.leaf_index[leaf];
+    sphere_test_lex(s0, id.x, o, d, tmax, best);
+    sphere_test_lex(s1, id.y, o, d, tmax, best);
+    sphere_test_lex(s2, id.z, o, d, tmax, best);
+    sphere_test_lex(s3, id.w, o, d, tmax, best);
+    ++tr.visits;
+    return bvh_pop(stack, tr.sp, tmax, tr.cur);
+}
+
+// Rays over budget: the wave scans all spheres for each of them in turn (every lane of the wave
+// must call this; `over_budget` marks the lanes whose (tmax, best) is a partial result).
+PT_DEV void bvh_finish_over_budget(const float4 *sph, uint32_t n_prims, bool over_budget, V3 o, V3 d, float &tmax,
+                                   int &best)
+{
     unsigned long long pending = __ballot(over_budget);
     const uint32_t lane = __lane_id();
     while (pending) {
@@ -299,6 +301,42 @@ PT_DEV void intersect_bvh(const BvhParams &B, const float4 *sph, uint32_t n_prim
         }
         if ((int)lane == src) { tmax = ct; best = cb; }
     }
+}
+
+PT_DEV void intersect_bvh(const BvhParams &B, const float4 *sph, uint32_t n_prims, uint2 *stack, int tid,
+                          bool active, V3 o, V3 d, float &tmax, int &best)
+{
+    BvhTraversal tr;
+    bool more = false;
+    if (active) more = bvh_begin(B, o, d, tmax, best, tr);
+    stack += tid;
+    bool over_budget = false;
+#ifdef PT_BVH_STATS
+    uint32_t st_nodes = 0, st_leaves = 0, st_wave_nodes = 0, st_wave_leaves = 0;
+    const bool st_leader = (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1;
+#define PT_BVH_COUNT(x) (++(x))
+#define PT_BVH_WAVE_COUNT(x) do { if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) ++(x); } while (0)
+#else
+#define PT_BVH_COUNT(x) ((void)0)
+#define PT_BVH_WAVE_COUNT(x) ((void)0)
+#endif
+    while (more) {
+#pragma unroll 1
+        for (int k = 0; k < kBvhNodeStepsPerLeafStep; ++k) {
+            if (more && tr.cur >= 0) {
+                PT_BVH_COUNT(st_nodes);
+                PT_BVH_WAVE_COUNT(st_wave_nodes);
+                more = bvh_node_step(B, stack, o, tmax, tr);
+                if (tr.visits > B.budget) { over_budget = more; more = false; }
+            }
+        }
+        if (more && tr.cur < 0) {
+            PT_BVH_COUNT(st_leaves);
+            PT_BVH_WAVE_COUNT(st_wave_leaves);
+            more = bvh_leaf_step(B, stack, o, d, tmax, best, tr);
+        }
+    }
+    bvh_finish_over_budget(sph, n_prims, over_budget, o, d, tmax, best);
 #ifdef PT_BVH_STATS
     if (active) {
         atomicAdd(B.stats + 0, (unsigned long long)st_nodes);
@@ -307,7 +345,7 @@ PT_DEV void intersect_bvh(const BvhParams &B, const float4 *sph, uint32_t n_prim
         if (over_budget) atomicAdd(B.stats + 3, 1ull);
         atomicAdd(B.stats + 4, (unsigned long long)st_wave_nodes);
         atomicAdd(B.stats + 5, (unsigned long long)st_wave_leaves);
-        if (refine) atomicAdd(B.stats + 7, 1ull);
+        if (tr.refine) atomicAdd(B.stats + 7, 1ull);
         atomicAdd(B.stats + 8 + (31 - __clz((int)(st_nodes + st_leaves + 1))), 1ull);   // log2 histogram of steps
     }
     if (st_leader) atomicAdd(B.stats + 6, 1ull);

@@ -144,12 +144,17 @@ int pt_set_row_bands(pt_handle h, uint32_t band_rows, uint32_t rank, uint32_t wo
 int pt_ray_count(pt_handle h, uint64_t *out);
 int pt_reset_counters(pt_handle h);
 /* Kernel variant; results are bit-identical in all of them.
- *   PT_VARIANT_REGENERATION (default): megakernel, persistent lanes with path regeneration
+ *   PT_VARIANT_AUTO (default): PT_VARIANT_WAVEFRONT for scenes rendered through the sphere BVH
+ *     (when no row bands are set and the integrator is PT_INTEGRATOR_PATH), else
+ *     PT_VARIANT_REGENERATION
+ *   PT_VARIANT_REGENERATION: megakernel, persistent lanes with path regeneration
  *   PT_VARIANT_CLASSIC: megakernel, a wave starts new paths only when all its lanes are idle
  *   2..64: megakernel, regeneration once that many lanes of a wave are idle (experiments)
  *   PT_VARIANT_WAVEFRONT: one launch per bounce over compacted path queues in device memory
- *     (allocates about 4 GiB of queues on first use; no row bands) */
-enum { PT_VARIANT_REGENERATION = 0, PT_VARIANT_CLASSIC = 1, PT_VARIANT_WAVEFRONT = 100 };
+ *     (allocates about 4 GiB of queues on first use; no row bands).  BVH scenes: persistent
+ *     waves that refill idle lanes from the queue while the other lanes keep traversing;
+ *     PT_VARIANT_WAVEFRONT + 1 switches that off, + 2..64 sets the refill threshold (experiments) */
+enum { PT_VARIANT_AUTO = -1, PT_VARIANT_REGENERATION = 0, PT_VARIANT_CLASSIC = 1, PT_VARIANT_WAVEFRONT = 100 };
 int pt_set_kernel_variant(pt_handle h, int variant);
 /* Integrator.
  *   PT_INTEGRATOR_PATH (default): Trace as the reference runs it, pathtracer.cu:112-170.

@@ -217,6 +217,47 @@ def test_visit_budget_does_not_change_results(pt, O, torch_cuda, budget):
         tr.Release()
 
 
+@pytest.mark.parametrize("size", [(16, 16), (200, 120), (333, 77)])
+def test_wavefront_dynamic_fetch_and_auto_variant(pt, O, torch_cuda, size):
+    """BVH scenes default to the queue-fed persistent waves (PT_VARIANT_AUTO); every way of
+    scheduling paths onto lanes gives the same bits: forced megakernel, static chunks (101),
+    refill thresholds 2 and 64, the default."""
+    rng = np.random.default_rng(31)
+    mats = materials(pt, [(0, 0.0), (1, 0.9), (2, 1.33), (0, 0.0)])
+    walls, lights = room(pt, (0, 40, -20), 60)
+    sph = np.concatenate([walls, cloud(pt, rng, 2500, (0, 40, -20), 50, 0.4, 2.0, 4)])
+    cam = pt.Camera([0, 45, 35], [0, 38, -20], [0, 1, 0], size[0], size[1], 0, 0, 60.0)
+    imgs, rays = {}, {}
+    for variant in (pt.VARIANT_AUTO, 0, 100, 101, 102, 164):
+        tr = pt.Pathtracer(cam, 8, 9)
+        tr.Init(mats, sph, lights)
+        if variant != pt.VARIANT_AUTO:
+            tr.SetKernelVariant(variant)
+        tr.ResetCounters()
+        imgs[variant] = render(torch_cuda, tr, 2, 3).cpu().numpy().tobytes()   # iterations 2..4
+        rays[variant] = tr.RayCount()
+        if variant == pt.VARIANT_AUTO:
+            # auto falls back to the megakernel where the wavefront variant cannot serve
+            tr.SetRowBands(16, 0, 1)
+            tr.SetIntegrator(pt.INTEGRATOR_NEE_MIS)
+            render(torch_cuda, tr, 1, 1)
+        tr.Release()
+    assert len(set(imgs.values())) == 1 and len(set(rays.values())) == 1
+    ref, _, _, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, 9, 8, first_iteration=2, n_iterations=3,
+                                          rect=(0, size[1] // 2, size[0], size[1] // 2 + 2), n_threads=8)
+    got = np.frombuffer(imgs[0], np.float32).reshape(size[1], size[0], 3)
+    # rows of a resumed range: the oracle accumulates from a zero buffer, so compare via a fresh GPU run
+    tr = pt.Pathtracer(cam, 8, 9)
+    tr.Init(mats, sph, lights)
+    buf = torch_cuda.zeros(size[0] * size[1] * 3, device="cuda")
+    tr.SetIteration(1)
+    tr.RunN(buf, 3)
+    assert buf.cpu().numpy().tobytes() == imgs[0]
+    rows = slice(size[1] // 2, size[1] // 2 + 2)
+    assert got[rows].tobytes() == ref[rows].tobytes()
+    tr.Release()
+
+
 def test_small_scenes_have_no_bvh(pt, torch_cuda):
     mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_MIXED)
     tr = pt.Pathtracer(pt.Camera(eye, look, up, 32, 32, 0, 0, fov), 4, 1)
