@@ -119,7 +119,7 @@ def main():
                     help="kernel variant (-1 auto: wavefront for BVH scenes, else 0; 0 regeneration megakernel, "
                          "1 classic megakernel, 100 wavefront)")
     ap.add_argument("--accel", default="auto", choices=["auto", "brute"],
-                    help="scenes above 512 spheres: sphere BVH (auto) or the reference's linear scan (brute)")
+                    help="scenes above 192 spheres: sphere BVH (auto) or the reference's linear scan (brute)")
     ap.add_argument("--integrator", default="path", choices=["path", "nee"],
                     help="path: the reference's Trace (the headline metric); nee: opt-in direct-light sampling "
                          "with MIS (bounces then include the shadow rays)")

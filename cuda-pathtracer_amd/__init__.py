@@ -286,7 +286,7 @@ class Pathtracer:
         self._check(self._lib.pt_set_integrator(self._h, integrator))
 
     def SetAccel(self, mode: int) -> None:
-        """ACCEL_AUTO: sphere BVH for scenes above 512 spheres; ACCEL_BRUTE_FORCE: linear scan."""
+        """ACCEL_AUTO: sphere BVH for scenes above 192 spheres; ACCEL_BRUTE_FORCE: linear scan."""
         self._check(self._lib.pt_set_accel(self._h, mode))
 
     def SetAccelBudget(self, visits: int) -> None:

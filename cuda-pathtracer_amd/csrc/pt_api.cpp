@@ -310,7 +310,7 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
     PT_HIP(h, hipMemcpy(h->d_light, light.data(), light.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(h, hipMemcpy(h->d_mat_type, mtype.data(), mtype.size() * sizeof(int), hipMemcpyHostToDevice));
     h->n_prims = n_spheres; h->n_mats = n_materials; h->n_lights = n_lights;
-    if (n_spheres > kMaxResidentSpheres) {
+    if (n_spheres > kBvhMinSpheres) {
         const int rc = upload_bvh(h, sph, spheres, n_spheres);
         if (rc != PT_OK) { free_scene(h); return rc; }
     }

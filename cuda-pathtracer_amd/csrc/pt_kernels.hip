@@ -254,7 +254,7 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y
     // Small resident scenes keep a camera-ray ring (p.small_scene_opts bit 0; experiments can
     // switch it off).  A branch-free variant of the scan was measured 3.5 % slower and dropped.
     const bool ring = !tiled && p.scene.n_prims <= kMaxRingSpheres && (p.small_scene_opts & 1);
-    const bool bvh = tiled && p.scene.bvh.n_nodes > 0;
+    const bool bvh = p.scene.bvh.n_nodes > 0;   // BVH kernels read the scene from global memory
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : render_lds_bytes(p.scene, tiled, ring);
 #define PT_LAUNCH(T, R, G, B) hipLaunchKernelGGL((render_kernel<T, R, G, B>), grid, block, lds, stream, p)
     if (bvh) {

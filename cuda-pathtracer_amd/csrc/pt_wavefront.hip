@@ -299,7 +299,7 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
     // sub-queue is shorter than its first chunk.
     const uint32_t chunks = p.sub_capacity / kBlockThreads;
     const dim3 grid(kWfSubQueues, chunks < 32u ? chunks : 32u), block(kBlockThreads);
-    const bool bvh = tiled && p.scene.bvh.n_nodes > 0;
+    const bool bvh = p.scene.bvh.n_nodes > 0;   // BVH kernels read the scene from global memory
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : scene_lds_bytes(p.scene, tiled);
     if (bvh && p.dynamic_fetch) {
         // one resident set of persistent workgroups (LDS: six per CU)

@@ -169,11 +169,11 @@ int pt_set_kernel_variant(pt_handle h, int variant);
  *     variants only. */
 enum { PT_INTEGRATOR_PATH = 0, PT_INTEGRATOR_NEE_MIS = 1 };
 int pt_set_integrator(pt_handle h, int integrator);
-/* Nearest-hit search of scenes with more than 512 spheres; results are bit-identical.
+/* Nearest-hit search of scenes with more than 192 spheres; results are bit-identical.
  *   PT_ACCEL_AUTO (default): sphere BVH built by pt_init_scene -- the acceleration structure
  *     the reference leaves as "TODO kd-tree" (scene.h:33) -- when the scene allows one
  *   PT_ACCEL_BRUTE_FORCE: the reference's linear scan over all spheres (scene.h:71-94),
- *     streamed through LDS in tiles
+ *     (from LDS; streamed through it in tiles above 512 spheres)
  * pt_accel_nodes returns the number of BVH nodes the scene got (0: none, the scan is used). */
 enum { PT_ACCEL_AUTO = 0, PT_ACCEL_BRUTE_FORCE = 1 };
 int pt_set_accel(pt_handle h, int mode);

@@ -90,7 +90,8 @@ def test_matches_oracle_on_seeded_random_scenes(pt, O, torch_cuda):
     rng = np.random.default_rng(2024)
     eye, look, up = [0, 45, 79.5], [0, 35, 0], [0, 1, 0]
     for n, (w, h), mb, seed in [(1, (16, 16), 3, 1), (5, (40, 24), 6, 3), (33, (31, 17), 12, 2**40 + 5),
-                                (70, (24, 24), 20, 9), (600, (32, 16), 8, 77), (1500, (20, 20), 6, 5)]:
+                                (70, (24, 24), 20, 9), (300, (24, 20), 8, 13), (600, (32, 16), 8, 77),
+                                (1500, (20, 20), 6, 5)]:
         mats, sph, lights = _random_scene(rng, O, n) if n > 1 else _random_scene(rng, O, 2)
         if n == 1:
             sph = sph[:1].copy(); sph["light_id"] = 0; lights = lights[:1].copy()

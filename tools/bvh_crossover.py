@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Where does the sphere BVH start to beat the linear scan?  Renders clouds of n small spheres in
+the demo room at 1080p with both (PT_ACCEL_AUTO / PT_ACCEL_BRUTE_FORCE) and prints the times.
+Scenes of up to 512 spheres never get a BVH (they are scanned from LDS), so only n > 512 is
+informative; run on the GPU box:  python tools/bvh_crossover.py"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pt = importlib.import_module("cuda-pathtracer_amd")
+
+
+def main():
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
+    cam = pt.Camera(eye, look, up, 1920, 1080, 0, 0, fov)
+    buf = torch.zeros(1920 * 1080 * 3, device="cuda")
+    rng = np.random.default_rng(1)
+    for n in (40, 64, 100, 160, 250, 400, 520, 1000, 5000, 20000, 100000):
+        extra = np.zeros(n, pt.SPHERE_DTYPE)
+        extra["pos"] = np.column_stack([rng.uniform(-45, 45, n), rng.uniform(5, 75, n), rng.uniform(-75, 20, n)])
+        extra["radius"] = rng.uniform(0.3, 1.2, n) * (10000 / n) ** (1 / 3)   # same volume fraction
+        extra["material_id"] = rng.integers(1, 6, n)
+        extra["light_id"] = -1
+        scene = np.concatenate([sph, extra])
+        row = [f"n={n + len(sph):7d}"]
+        for accel, variant, label in ((pt.ACCEL_BRUTE_FORCE, 0, "scan"), (pt.ACCEL_AUTO, 0, "bvh megakernel"),
+                                      (pt.ACCEL_AUTO, -1, "bvh auto")):
+            if accel == pt.ACCEL_BRUTE_FORCE and n > 20000:
+                continue
+            tr = pt.Pathtracer(cam, 8, 1)
+            tr.Init(mats, scene, lights)
+            tr.SetAccel(accel)
+            tr.SetKernelVariant(variant)
+            its = 2
+            tr.RunN(buf, its)            # warm-up (allocates the queues)
+            tr.Reset(); tr.ResetCounters()
+            tr.RunN(buf, its)
+            ms = tr.LastKernelMs()
+            row.append(f"{label}: {ms / its:8.2f} ms/it {tr.RayCount() / ms / 1e6:7.3f} G/s (nodes {tr.AccelNodes()})")
+            tr.Release()
+        print("  ".join(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()
