@@ -211,29 +211,106 @@ PT_DEV float reflectance(V3 inc, V3 nor, float n1, float n2)
     return (rOrth * rOrth + rPar * rPar) / 2.0f;
 }
 
-// SampleMaterial, scene.h:177-221 with Material::F, material.h:37-43
+// SampleMaterial, scene.h:177-221 with Material::F, material.h:37-43.
+//
+// A wave executes every branch that any of its lanes takes, so the refraction branch -- a few
+// lanes per wave, but almost always some -- used to cost a fifth of the demo render.  The three
+// BSDFs are therefore evaluated in common stages: the expensive operations that the diffuse
+// branch needs anyway (one division, one square root, one normalisation) also serve the glass
+// lanes, and only what is left (two Fresnel quotients) runs for the glass lanes alone.  Every
+// value is produced by the same IEEE operations on the same operands as in the reference's
+// order; the identities used are exact in fp32:
+//   - n1/n2 is 1/coef from outside and coef/1 == coef from inside (scene.h:199-209);
+//   - x*1.f == x, so with n1 or n2 equal to 1 the two Fresnel quotients (globals.h:122-123) are
+//     X = (cosI - coef*cosT)/(cosI + coef*cosT) and Y = (coef*cosI - cosT)/(coef*cosI + cosT),
+//     (rOrth, rPar) = (X, Y) from outside and (Y, X) from inside, and X*X + Y*Y == Y*Y + X*X;
+//   - Refract's cost = wo.n is -cosI, so its cos2t = 1 - eta*eta*(1 - cost*cost) is the very
+//     value 1 - sinT2 whose root reflectance() already took: sqrt(cos2t) == cosT.
 PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &pdf, V3 n,
                           float su, float sv)
 {
+    const bool is_d = type == 0, is_s = type == 1, is_g = type == 2;
+
+    // ---- glass: side of the surface, scene.h:198-209 (nnor == n for the other materials)
+    const bool outside = dot(wo, n) < 0.f;
+    const bool flip = is_g && !outside;
+    const V3 nnor = mk(flip ? -n.x : n.x, flip ? -n.y : n.y, flip ? -n.z : n.z);
+
+    // ---- diffuse: ConcentricSampleDisk up to its division, montecarlo.h:76-114
+    const float sx = 2.f * su - 1.f;
+    const float sy = 2.f * sv - 1.f;
+    const bool upper = sx >= -sy;            // regions 1, 2
+    const bool r1 = upper && sx > sy;
+    const bool r2 = upper && !r1;
+    const bool r3 = !upper && sx <= sy;
+    const float num = (r1 || r3) ? sy : sx;
+    const float r = r1 ? sx : (r2 ? sy : (r3 ? -sx : -sy));
+    const float off = r1 ? (sy > 0.f ? 0.f : 8.f) : (r2 ? 2.f : (r3 ? 4.f : 6.f));
+
+    // ---- division 1: diffuse num/r | glass from outside 1/coef
+    const float q = pt_div(is_g ? 1.f : num, is_g ? coef : r);
+
+    float root_arg, cosI = 0.f, eta = 1.f;
+    bool tir = false;
+    V3 ret = mk(0.f, 0.f, 0.f);
+    if (is_g) {
+        // reflectance(), globals.h:117-121
+        eta = outside ? q : coef;
+        cosI = -(dot(nnor, wo));
+        const float sinT2 = eta * eta * (1.0f - cosI * cosI);
+        tir = sinT2 > 1.0f;
+        root_arg = tir ? 1.f : 1.0f - sinT2;   // total internal reflection: the root is not used
+    } else {
+        // montecarlo.h:115-117, 129-130
+        float theta = (r2 || r3) ? off - q : off + q;
+        theta *= PT_M_PI / 4.f;
+        float s, c;
+        pt_sincosf(theta, s, c);
+        const bool origin = sx == 0.f && sy == 0.f;   // montecarlo.h:85-89
+        ret.x = origin ? 0.f : r * c;
+        ret.y = origin ? 0.f : r * s;
+        const float e = 1.f - ret.x * ret.x - ret.y * ret.y;
+        root_arg = 0.f > e ? 0.f : e;
+    }
+
+    // ---- square root: diffuse z of the hemisphere sample | glass cosT
+    const float root = pt_sqrt(root_arg);
+
+    V3 vec;              // direction before normalisation
+    bool do_reflect = is_s;
+    if (is_g) {
+        // reflectance(), globals.h:122-125
+        const float cosT = root;
+        const float x = pt_div(cosI - coef * cosT, cosI + coef * cosT);
+        const float y = pt_div(coef * cosI - cosT, coef * cosI + cosT);
+        const float rr = outside ? (x * x + y * y) : (y * y + x * x);
+        const float refl = tir ? 1.0f : rr / 2.0f;
+        do_reflect = su < refl;
+        // Refract, globals.h:111-115, before its Normalize(): cost == -cosI, sqrt(cos2t) == cosT
+        vec = wo * eta - nnor * (eta * (-cosI) + cosT);
+    } else {
+        // RotateByNormal, montecarlo.h:120-124, before its Normalize()
+        ret.z = root;
+        const V3 w = n;
+        const V3 u = __builtin_fabsf(n.x) > __builtin_fabsf(n.z) ? mk(-n.y, n.x, 0.f) : mk(0.f, -n.z, n.y);
+        const V3 v = cross(w, u);
+        vec = (u * ret.x + v * ret.y) + w * ret.z;
+    }
+
+    // ---- normalisation (diffuse, refraction) or mirror direction (specular, Fresnel reflection)
+    if (do_reflect) wi = reflect(wo, nnor);
+    else            wi = normalize(vec);
+
     V3 f = mk(0.f, 0.f, 0.f);
-    if (type == 0) {
-        wi = cosine_sample_hemisphere(su, sv, n);
+    if (is_d) {
         pdf = dot(wo, wi) < 0.f ? __builtin_fabsf(dot(wi, n)) * PT_INV_PI : 0.f;
         f = f + color * PT_INV_PI;
-    } else if (type == 1) {
-        wi = reflect(wo, n);
+    } else if (is_s) {
         pdf = 1.f;
         f = color * coef;
-    } else if (type == 2) {
-        float n1, n2;
-        V3 nnor;
-        if (dot(wo, n) < 0.f) { n1 = 1.f; n2 = coef; nnor = n; }
-        else                  { n1 = coef; n2 = 1.f; nnor = -n; }
-        const float refl = reflectance(wo, nnor, n1, n2);
-        if (su < refl) wi = reflect(wo, nnor);
-        else           wi = refract(wo, nnor, pt_div(n1, n2));
-        f = color;
+    } else if (is_g) {
         pdf = 1.f;
+        f = color;
     } else {
         wi = mk(0.f, 0.f, 0.f);
         pdf = 0.f;
