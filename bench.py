@@ -31,7 +31,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# BASELINE.json configs[1], configs[3], configs[4]
+# the benchmark configurations of BASELINE.json: configs[1], configs[3], configs[4]
 WORKLOADS = {
     "demo1080": dict(scene="SCENE_DEMO", width=1920, height=1080, iterations=64, depth=8,
                      label="demo scene (9 spheres + area light) 1920x1080, 64 spp, depth 8"),

@@ -82,7 +82,7 @@ def main():
     ref = O.load_ref()
     assert ref.ref_uses_libm_sincos() == 0
 
-    # BASELINE config 1: demo scene 256x256, 1 iteration, depth 4
+    # the CPU-runnable benchmark configuration: demo scene 256x256, 1 iteration, depth 4
     case("demo_256x256_d4_it1", pt.SCENE_DEMO, 256, 256, 4, seed=1, store_paths=False, libm_stats=True)
     # the same at a size whose per-path data is small enough to commit
     case("demo_64x64_d4_it1", pt.SCENE_DEMO, 64, 64, 4, seed=1)
@@ -97,7 +97,7 @@ def main():
     # no primitives at all: every primary ray misses
     case("empty_16x16_d4_it1", None, 16, 16, 4, seed=1, scene=empty_scene())
 
-    # camera PODs derived by the reference's constructor at the sizes of the BASELINE configs
+    # camera PODs derived by the reference's constructor at the sizes of the benchmark configurations
     mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
     sizes = [(256, 256), (640, 480), (1920, 1080), (3840, 2160), (17, 5)]
     pods = np.concatenate([O.camera_init(eye, look, up, w, h, fov, lib=ref, fn="ref_camera_init")

@@ -97,7 +97,7 @@ def compare_accel(pt, torch, cam, mats, sph, lights, depth, seed=3, iterations=2
 
 
 def test_synth10k_bvh_equals_scan_and_golden(pt, torch_cuda):
-    """BASELINE config 4's scene at 1080p: BVH == tiled scan bit for bit, in both the
+    """The 10 007-sphere benchmark scene at 1080p: BVH == tiled scan bit for bit, in both the
     megakernel and the one-launch-per-bounce variant."""
     mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_SYNTH10K, 1)
     cam = pt.Camera(eye, look, up, 1920, 1080, 0, 0, fov)

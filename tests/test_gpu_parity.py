@@ -314,7 +314,7 @@ def test_errors(pt, torch_cuda):
 
 
 def test_full_size_properties_1080p(pt, O, torch_cuda):
-    """BASELINE's 1080p demo config through size-independent properties: determinism, iteration
+    """The headline benchmark configuration (demo scene, 1080p) through size-independent properties: determinism, iteration
     composition (2+2 == 4, bit-exact), ray count == per-path Intersect calls, and a sampled
     band of rows against the oracle."""
     mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
@@ -344,7 +344,7 @@ def test_full_size_properties_1080p(pt, O, torch_cuda):
 
 
 def test_config3_size_4k_tile_split_over_8_ranks(pt, torch_cuda):
-    """BASELINE config 3's frame (3840x2160) split into 16-row bands over 8 ranks: the sum of
+    """The 4K benchmark configuration's frame (3840x2160) split into 16-row bands over 8 ranks: the sum of
     the ranks' buffers is the 1-rank image bit for bit, and the ray counts add up."""
     mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
     cam = pt.Camera(eye, look, up, 3840, 2160, 0, 0, fov)
@@ -369,7 +369,7 @@ def test_config3_size_4k_tile_split_over_8_ranks(pt, torch_cuda):
 
 
 def test_config4_size_synth10k_1080p_rows_against_oracle(pt, O, torch_cuda):
-    """BASELINE config 4 (10 007 spheres, 1080p): one iteration through the LDS-tiled scan;
+    """The 10 007-sphere benchmark configuration at 1080p: one iteration through the LDS-tiled scan;
     four rows spread over the frame are compared with the oracle bit for bit."""
     mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_SYNTH10K, 1)
     cam = pt.Camera(eye, look, up, 1920, 1080, 0, 0, fov)

@@ -1,5 +1,5 @@
 """Direct-light sampling (NEE + MIS): the reference carries the building blocks but never calls
-them from Trace (SURVEY: SampleLight scene.h:150-170, Pdf scene.h:110-144, IntersectP
+them from Trace (SampleLight scene.h:150-170, Pdf scene.h:110-144, IntersectP
 scene.h:101-108, Primitive::Sample primitive.h:50-72, VisibilityTester light.h:23-32,
 UniformSampleSphere/Cone, UniformConePdf, PowerHeuristic montecarlo.h:135-159, CoordinateSystem
 geometry.h:548-558, Material::F material.h:37-43).
