@@ -222,7 +222,7 @@ def main():
     # run from inside the benchmark): profiles/pmc_traffic_<workload>_v<variant>.json
     traffic = None
     tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}{'_bvh' if bvh else ''}_v{eff_variant}.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and args.integrator == "path":
         with open(tpath) as f:
             traffic = json.load(f).get("hbm_bytes_per_step")
     achieved = rays_per_launch * fpr / (launch_ms * 1e-3) / 1e12 if fpr else None
