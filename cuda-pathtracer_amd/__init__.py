@@ -71,6 +71,7 @@ ABI = [
     ("pt_accel_nodes", _u32, [_vp]),
     ("pt_set_accel_budget", _i32, [_vp, _u32]),
     ("pt_accel_stats", _i32, [_vp, _pu64]),
+    ("pt_debug_build_bvh", _i32, [_vp, _u32, _pu32, _vp, _vp, _vp]),
     ("pt_last_kernel_ms", _i32, [_vp, _pf]),
     ("pt_read_image", _i32, [_vp, _vp, _vp]),
     ("pt_debug_trace", _i32, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _pu64]),
@@ -207,6 +208,24 @@ def build_scene(scene_id: int = SCENE_DEMO, seed: int = 1):
     if rc != PT_OK:
         raise PtError(rc, "pt_scene_build failed")
     return mats, sph, lights, (eye, look_at, up, float(fov.value))
+
+
+def debug_build_bvh(spheres):
+    """Host-side BVH of `spheres` as pt_init_scene would build it (no device needed).
+    Returns None when no hierarchy is built, else a dict: nodes [n,16] float32 (child boxes and
+    references, device layout), leaf_index [leaves,4], big_index, depth."""
+    lib = load_library()
+    sph = np.ascontiguousarray(spheres, SPHERE_DTYPE)
+    counts = (_u32 * 4)()
+    if lib.pt_debug_build_bvh(_ptr(sph), len(sph), counts, None, None, None) != PT_OK:
+        raise ValueError("pt_debug_build_bvh: invalid arguments")
+    if counts[0] == 0:
+        return None
+    nodes = np.zeros((counts[0], 16), np.float32)
+    leaf = np.zeros((counts[1], 4), np.int32)
+    big = np.zeros(counts[2], np.int32)
+    lib.pt_debug_build_bvh(_ptr(sph), len(sph), counts, _ptr(nodes), _ptr(leaf), _ptr(big))
+    return {"nodes": nodes, "leaf_index": leaf, "big_index": big, "depth": int(counts[3])}
 
 
 class Pathtracer:

@@ -384,6 +384,32 @@ int pt_set_accel(pt_handle h, int mode)
 
 uint32_t pt_accel_nodes(pt_handle h) { return h ? h->bvh.n_nodes : 0; }
 
+int pt_debug_build_bvh(const pt_sphere *spheres, uint32_t n_spheres, uint32_t counts[4], float *nodes,
+                       int32_t *leaf_index, int32_t *big_index)
+{
+    if (!counts || (n_spheres && !spheres)) return PT_ERR_INVALID;
+    std::vector<float4> sph(n_spheres);
+    std::vector<float> radius(n_spheres);
+    for (uint32_t i = 0; i < n_spheres; ++i) {
+        sph[i] = make_float4(spheres[i].pos[0], spheres[i].pos[1], spheres[i].pos[2], spheres[i].radius * spheres[i].radius);
+        radius[i] = spheres[i].radius;
+    }
+    BvhData d;
+    const bool built = build_bvh(sph.data(), radius.data(), n_spheres, &d);
+    const bool fill = built && counts[0] == d.nodes.size() / 4 && counts[1] == d.leaf_index.size() / kBvhLeafSize &&
+                      counts[2] == d.big_index.size();
+    if (fill) {
+        if (nodes) memcpy(nodes, d.nodes.data(), d.nodes.size() * sizeof(float4));
+        if (leaf_index) memcpy(leaf_index, d.leaf_index.data(), d.leaf_index.size() * sizeof(int));
+        if (big_index && !d.big_index.empty()) memcpy(big_index, d.big_index.data(), d.big_index.size() * sizeof(int));
+    }
+    counts[0] = built ? (uint32_t)(d.nodes.size() / 4) : 0;
+    counts[1] = built ? (uint32_t)(d.leaf_index.size() / kBvhLeafSize) : 0;
+    counts[2] = built ? (uint32_t)d.big_index.size() : 0;
+    counts[3] = built ? d.depth : 0;
+    return PT_OK;
+}
+
 int pt_set_accel_budget(pt_handle h, uint32_t visits)
 {
     if (!h) return PT_ERR_INVALID;

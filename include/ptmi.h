@@ -183,6 +183,14 @@ uint32_t pt_accel_nodes(pt_handle h);
  * boxes must be widened enormously).  0 restores the default, max(64, spheres / 80), set by
  * pt_init_scene.  A tuning and test knob. */
 int pt_set_accel_budget(pt_handle h, uint32_t visits);
+/* Test hook, host only (no device needed): builds the BVH pt_init_scene would build for these
+ * spheres, whatever their number.  counts = {inner nodes, leaves, always-tested spheres, depth}
+ * on return, all 0 when no hierarchy is built.  The arrays (may be NULL) are filled only when
+ * counts holds the first three values on entry: nodes [inner nodes][16] floats (two child boxes
+ * and two child references as laid out in device memory), leaf_index [leaves][4] sphere indices
+ * (0x7fffffff = empty slot), big_index [always-tested].  Call once to size, once to fill. */
+int pt_debug_build_bvh(const pt_sphere *spheres, uint32_t n_spheres, uint32_t counts[4], float *nodes,
+                       int32_t *leaf_index, int32_t *big_index);
 /* Traversal counters since the last call (only libraries built with -DPT_BVH_STATS count -- the
  * counting costs time -- others return zeros):
  *   [0] inner nodes visited  [1] leaves visited  [2] rays traversed  [3] rays finished by the wave-wide scan

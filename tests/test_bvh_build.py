@@ -1,0 +1,90 @@
+"""Host-side build of the sphere BVH (csrc/pt_bvh.cpp) through the pt_debug_build_bvh test hook:
+structural invariants the traversal relies on.  No device needed."""
+import numpy as np
+import pytest
+
+
+def scene(pt, rng, n, half=50.0, rmin=0.3, rmax=1.2, n_big=6):
+    s = np.zeros(n + n_big, pt.SPHERE_DTYPE)
+    s["pos"][:n_big] = rng.normal(size=(n_big, 3)) * 1e5
+    s["radius"][:n_big] = 1e5
+    s["pos"][n_big:] = rng.uniform(-half, half, (n, 3))
+    s["radius"][n_big:] = rng.uniform(rmin, rmax, n)
+    s["light_id"] = -1
+    return s
+
+
+def check(pt, sph):
+    b = pt.debug_build_bvh(sph)
+    if b is None:
+        return None
+    nodes, leaf, big = b["nodes"], b["leaf_index"], b["big_index"]
+    refs = nodes[:, 12:14].copy().view(np.int32)
+    # every sphere is in exactly one leaf slot or in the always-tested list
+    used = leaf[leaf != 0x7fffffff]
+    everything = np.sort(np.concatenate([used, big]))
+    assert np.array_equal(everything, np.arange(len(sph)))
+    # every inner node except the root and every leaf is referenced exactly once
+    inner_refs = np.sort(refs[refs >= 0])
+    assert np.array_equal(inner_refs, np.arange(1, len(nodes)))
+    leaf_refs = np.sort(~refs[refs < 0])
+    assert np.array_equal(leaf_refs, np.arange(len(leaf)))
+    # child boxes contain the spheres below them; depth is what the stack is sized for
+    lo = np.stack([nodes[:, 0:3], nodes[:, 6:9]], 1)              # [node][child][xyz]
+    hi = np.stack([np.column_stack([nodes[:, 3], nodes[:, 4], nodes[:, 5]]), nodes[:, 9:12]], 1)
+
+    def walk(ref, depth):
+        if ref < 0:
+            idx = leaf[~ref]
+            idx = idx[idx != 0x7fffffff]
+            c, r = sph["pos"][idx].astype(np.float64), np.abs(sph["radius"][idx].astype(np.float64))
+            return (c - r[:, None]).min(0), (c + r[:, None]).max(0), 0
+        d = 0
+        mins, maxs = [], []
+        for k in (0, 1):
+            cl, ch, cd = walk(int(refs[ref, k]), depth + 1)
+            assert (lo[ref, k] <= cl).all() and (hi[ref, k] >= ch).all(), (ref, k)
+            # ... and not by much: slack is 1e-4 + 1e-6 of the cloud's size
+            tol = 0.01 + 1e-5 * max(np.abs(cl).max(), np.abs(ch).max())
+            assert (cl - lo[ref, k]).max() < tol and (hi[ref, k] - ch).max() < tol
+            mins.append(cl); maxs.append(ch); d = max(d, cd)
+        return np.minimum(*mins), np.maximum(*maxs), d + 1
+
+    _, _, depth = walk(0, 0)
+    assert depth == b["depth"] <= 28
+    return b
+
+
+def test_invariants_on_random_scenes(pt):
+    rng = np.random.default_rng(1)
+    assert check(pt, scene(pt, rng, 5)) is not None      # few spheres of very different sizes
+    for n in (193, 1000, 10000):
+        b = check(pt, scene(pt, rng, n))
+        assert b is not None and len(b["big_index"]) == 6
+        assert len(b["leaf_index"]) >= n / 4
+        assert b["depth"] <= np.ceil(np.log2(max(n / 4, 1))) + 1      # median splits: balanced
+
+
+def test_degenerate_inputs(pt):
+    rng = np.random.default_rng(2)
+    s = scene(pt, rng, 500)
+    s["pos"][6:] = [1.0, 2.0, 3.0]                   # all centres coincide
+    check(pt, s)
+    s = scene(pt, rng, 500)
+    s["pos"][6:, 1] = 0.0                            # coplanar
+    s["pos"][6:, 0] = np.round(s["pos"][6:, 0])      # many equal coordinates on the split axis
+    check(pt, s)
+    s = scene(pt, rng, 300)
+    s["radius"][10] = -2.0                           # the sphere test only sees r*r
+    s["radius"][11] = 0.0
+    check(pt, s)
+    s = scene(pt, rng, 300)
+    s["radius"][20] = np.inf
+    s["pos"][21] = [np.nan, 0, 0]
+    b = check(pt, s)
+    assert {20, 21} <= set(b["big_index"].tolist())  # unboundable: always tested
+    # too many spheres that are far larger than the rest: no hierarchy, the scan is used
+    s = scene(pt, rng, 400, n_big=80)
+    assert pt.debug_build_bvh(s) is None
+    assert pt.debug_build_bvh(scene(pt, rng, 3, n_big=0)) is None
+    assert pt.debug_build_bvh(np.zeros(0, pt.SPHERE_DTYPE)) is None
