@@ -31,14 +31,17 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# the benchmark configurations of BASELINE.json: configs[1], configs[3], configs[4]
+# the benchmark configurations of BASELINE.json: configs[1] (the headline), configs[2..4]
 WORKLOADS = {
     "demo1080": dict(scene="SCENE_DEMO", width=1920, height=1080, iterations=64, depth=8,
-                     label="demo scene (9 spheres + area light) 1920x1080, 64 spp, depth 8"),
+                     label="demo scene (9 spheres + area light) 1920x1080, 64 iterations of 4 paths per pixel, depth 8"),
+    # configs[2]: 3840x2160, 1024 spp over 8 GPUs under the sample-range split = 128 iterations per GPU
+    "demo4k": dict(scene="SCENE_DEMO", width=3840, height=2160, iterations=128, depth=8,
+                   label="demo scene (9 spheres + area light) 3840x2160, 128 iterations of 4 paths per pixel per GPU, depth 8"),
     "synth10k": dict(scene="SCENE_SYNTH10K", width=1920, height=1080, iterations=16, depth=8,
-                     label="synthetic 10 007-sphere scene 1920x1080, 16 spp, depth 8"),
+                     label="synthetic 10 007-sphere scene 1920x1080, 16 iterations of 4 paths per pixel, depth 8"),
     "mixed16": dict(scene="SCENE_MIXED", width=1920, height=1080, iterations=32, depth=16,
-                    label="mixed diffuse/specular/glass grid 1920x1080, 32 spp, depth 16"),
+                    label="mixed diffuse/specular/glass grid 1920x1080, 32 iterations of 4 paths per pixel, depth 16"),
 }
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (256 CU x 256 flop/clk x 2.4 GHz)
 
