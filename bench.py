@@ -11,7 +11,9 @@ resident in HBM.
 
 N > 1 (one process per GPU, launched by torch.distributed.run): sample-range split -- every
 rank renders the same frame for its own block of iterations into a SUM buffer (per-GPU work
-fixed: weak scaling) and one RCCL reduce of the accumulation buffers ends the step.
+fixed: weak scaling) and one RCCL reduce of the accumulation buffers ends the step.  Steps
+alternate between two buffers, so the reduce of step k (on RCCL's stream) runs while step k+1
+renders; the timed region ends when every reduce has completed.
 
 Adds to the JSON line:
   roofline      FP32 vector-ALU roofline of the render kernel: algorithmic flops per launch
@@ -129,6 +131,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Libraries print banners on stdout (RCCL its version block, gloo its connection report):
+    # everything but the result line goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -144,8 +152,12 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # PT_BENCH_SINGLE_RANK_PG=1: initialise the process group and issue the collectives even with
+    # one rank (a rehearsal of the RCCL calls of the N>1 path on a one-GPU box)
+    grouped = world > 1 or os.environ.get("PT_BENCH_SINGLE_RANK_PG") == "1"
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -165,34 +177,54 @@ def main():
     # what PT_VARIANT_AUTO resolves to (pt_set_kernel_variant in include/ptmi.h)
     eff_variant = args.variant if args.variant >= 0 else (100 if bvh and args.integrator == "path" else 0)
     tr.SetStream(torch.cuda.current_stream().cuda_stream)
-    if world > 1:
+    if grouped:
         tr.SetAccumMode(pt.ACCUM_SUM)
-    buf = torch.zeros(wl["width"] * wl["height"] * 3, dtype=torch.float32, device=device)
+    # N > 1: two accumulation buffers, so that the reduce of one step (on RCCL's stream) overlaps
+    # with the render of the next step into the other buffer
+    n_px = wl["width"] * wl["height"] * 3
+    bufs = [torch.zeros(n_px, dtype=torch.float32, device=device) for _ in range(2 if grouped else 1)]
+    buf = bufs[0]
+    pending = [None] * len(bufs)
     first, n_it = sharding.sample_range(rank, world, wl["iterations"])
+    step_no = [0]
+
+    def finish(slot):
+        """The reduce that last used bufs[slot] is complete (as seen by the current stream) and the
+        root has turned the sum into the mean."""
+        if pending[slot] is not None:
+            pending[slot].wait()
+            if rank == 0:
+                bufs[slot].mul_(1.0 / float(world * n_it))
+            pending[slot] = None
 
     def step():
+        slot = step_no[0] % len(bufs)
+        step_no[0] += 1
+        finish(slot)
         tr.Reset()
         tr.SetIteration(first - 1)
-        tr.RunN(buf, n_it, sync=False)
-        if world > 1:
+        tr.RunN(bufs[slot], n_it, sync=False)
+        if grouped:
             if backend == "nccl":
-                sharding.reduce_to_root(buf, dist, 0)
+                pending[slot] = sharding.reduce_to_root(bufs[slot], dist, 0, async_op=True, single_rank_too=True)
             else:
-                host = buf.cpu()
-                sharding.reduce_to_root(host, dist, 0)
-                buf.copy_(host)
-            if rank == 0:
-                buf.mul_(1.0 / float(world * n_it))
+                host = bufs[slot].cpu()
+                sharding.reduce_to_root(host, dist, 0, single_rank_too=True)
+                bufs[slot].copy_(host)
+                if rank == 0:
+                    bufs[slot].mul_(1.0 / float(world * n_it))
 
     def fence():
+        for slot in range(len(bufs)):
+            finish(slot)
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
     def all_reduce_scalar(value, op):
         t = torch.tensor([value], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        if world > 1:
+        if grouped:
             dist.all_reduce(t, op=op)
         return float(t.item())
 
@@ -218,7 +250,7 @@ def main():
     # Average launch duration of the render kernel: at N=1 the timed region is nothing but the
     # K launches, so the event pair around it gives it directly; with a reduce in the step the
     # library's own event pair around the last launch is used instead.
-    launch_ms = region_ms / args.steps if world == 1 else tr.LastKernelMs()
+    launch_ms = region_ms / args.steps if not grouped else tr.LastKernelMs()
     rays_per_launch = rays_local / max(1, args.steps)
     fpr = flops_per_ray_bvh(args.workload) if bvh else flops_per_ray(len(sph))
     # HBM bytes per step from the committed PMC passes of this same command (rocprofv3 cannot be
@@ -244,7 +276,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["label"], "paths_per_step_per_gpu": wl["width"] * wl["height"] * 4 * n_it,
                        "bounces_per_step_per_gpu": rays_per_launch, "spheres": int(len(sph)),
-                       "parallelism": "single" if world == 1 else f"sample-range split x{world} + RCCL reduce(sum)",
+                       "parallelism": "single" if world == 1 else
+                                      f"sample-range split x{world} + RCCL reduce(sum) overlapped with the next render",
                        "kernel_variant": eff_variant,
                        "nearest_hit": "sphere BVH" if bvh else "linear scan", "integrator": args.integrator},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
@@ -254,16 +287,19 @@ def main():
                          "launch_ms": launch_ms,
                          "flops_per_bounce": fpr, "bounces_per_launch": rays_per_launch},
         }
-        if world == 1 and not args.no_cpu_baseline and args.integrator == "path":
+        if not grouped and not args.no_cpu_baseline and args.integrator == "path":
             def gpu_render(n):
                 tr.Reset()
                 tr.RunN(buf, n, sync=True)
                 return buf.cpu().numpy().reshape(wl["height"], wl["width"], 3)
             out["cpu_baseline"] = cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
     tr.Release()
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -33,11 +33,18 @@ def owned_bands(height: int, band_rows: int, rank: int, world: int):
     return [(b * band_rows, min(height, (b + 1) * band_rows)) for b in range(rank, n_bands, world)]
 
 
-def reduce_to_root(buffer, dist=None, dst: int = 0):
-    """Sum the accumulation buffers of all ranks into rank `dst` (in place)."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(buffer, dst=dst, op=dist.ReduceOp.SUM)
-    return buffer
+def reduce_to_root(buffer, dist=None, dst: int = 0, async_op: bool = False, single_rank_too: bool = False):
+    """Sum the accumulation buffers of all ranks into rank `dst` (in place).
+
+    async_op=True returns the collective's work handle (or None when there is nothing to reduce):
+    the reduce then runs on the backend's own stream behind the work already enqueued on the
+    current stream, so the next render (into ANOTHER buffer) overlaps with it; call .wait() on
+    the handle before the buffer is read or rendered into again.  single_rank_too issues the
+    collective even in a group of one (a rehearsal of the RCCL path on a one-GPU box)."""
+    work = None
+    if dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_too):
+        work = dist.reduce(buffer, dst=dst, op=dist.ReduceOp.SUM, async_op=async_op)
+    return work if async_op else buffer
 
 
 def render_sample_split(render_sum: Callable, rank: int, world: int, iterations_per_rank: int,
