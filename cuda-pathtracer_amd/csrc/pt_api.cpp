@@ -77,6 +77,28 @@ static int fail(pt_context *h, int code, const char *fmt, ...)
             return fail((h), PT_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_));    \
     } while (0)
 
+// An instance belongs to the device that was current at pt_create (pt_context::device).  Every
+// entry point that reaches the HIP runtime makes that device current for the duration of the
+// call, so a process that drives several devices may call in with any device current.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+// Scenes are staged whole in LDS (spheres, materials, lights) when they are small enough;
+// otherwise spheres stream through an LDS tile and the rest is read from device memory.
+static bool scene_streams(const SceneParams &s)
+{
+    return s.n_prims > kMaxResidentSpheres || scene_lds_bytes(s, false) > kMaxResidentBytes;
+}
+
 static bool camera_ok(const pt_camera_pod *c)
 {
     return c && c->width > 0 && c->height > 0 && (uint64_t)c->width * c->height <= 0x7fffffffull / 3;
@@ -232,6 +254,7 @@ static void free_wavefront(pt_context *h)
 int pt_destroy(pt_handle h)
 {
     if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     (void)hipStreamSynchronize(h->stream);
     free_scene(h);
     free_wavefront(h);
@@ -248,6 +271,7 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
                   const pt_light *lights, uint32_t n_lights)
 {
     if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     if ((n_materials && !materials) || (n_spheres && !spheres) || (n_lights && !lights))
         return fail(h, PT_ERR_INVALID, "pt_init_scene: NULL array with non-zero count");
     if (n_spheres > 0x7fffffffu / 2) return fail(h, PT_ERR_INVALID, "pt_init_scene: too many spheres");
@@ -421,6 +445,7 @@ int pt_set_accel_budget(pt_handle h, uint32_t visits)
 int pt_accel_stats(pt_handle h, uint64_t out[32])
 {
     if (!h || !out) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     memset(out, 0, 32 * sizeof(uint64_t));
     if (!h->d_bvh) return PT_OK;
     PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -543,7 +568,7 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
     p.accum_mode = h->accum_mode;
     p.buffer = dbuf;
     p.ray_counter = h->d_ray_counter;
-    const bool tiled = p.scene.n_prims > kMaxResidentSpheres;
+    const bool tiled = scene_streams(p.scene);
 
     PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
     uint32_t done = 0;
@@ -606,7 +631,7 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
         p.band_rows = div_up(p.cam.height, 16) * 16; p.band_rank = 0; p.band_world = 1;
         grid_y = p.band_rows / 16;
     }
-    const bool tiled = p.scene.n_prims > kMaxResidentSpheres;
+    const bool tiled = scene_streams(p.scene);
     if (grid_y > 0) {
         PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
         if (h->integrator == PT_INTEGRATOR_NEE_MIS)
@@ -624,6 +649,7 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
 int pt_run_n(pt_handle h, float *device_buffer, uint32_t n_iterations, int sync)
 {
     if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     int rc = enqueue(h, device_buffer, n_iterations);
     if (rc != PT_OK) return rc;
     if (sync) PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -633,6 +659,7 @@ int pt_run_n(pt_handle h, float *device_buffer, uint32_t n_iterations, int sync)
 int pt_run(pt_handle h, float *buffer, int buffer_is_device)
 {
     if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     if (!buffer) return fail(h, PT_ERR_INVALID, "pt_run: buffer is NULL");
     if (buffer_is_device) return pt_run_n(h, buffer, 1, 1);
 
@@ -651,6 +678,7 @@ int pt_run(pt_handle h, float *buffer, int buffer_is_device)
 int pt_read_image(pt_handle h, const float *device_buffer, float *host_rgb)
 {
     if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     if (!device_buffer || !host_rgb) return fail(h, PT_ERR_INVALID, "pt_read_image: NULL pointer");
     const size_t bytes = (size_t)h->camera.width * h->camera.height * 3 * sizeof(float);
     PT_HIP(h, hipMemcpyAsync(host_rgb, device_buffer, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -701,6 +729,7 @@ int pt_save_checkpoint(pt_handle h, const float *device_buffer, const char *path
 int pt_load_checkpoint(pt_handle h, float *device_buffer, const char *path)
 {
     if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     if (!device_buffer || !path) return fail(h, PT_ERR_INVALID, "pt_load_checkpoint: NULL argument");
     FILE *f = fopen(path, "rb");
     if (!f) return fail(h, PT_ERR_INVALID, "pt_load_checkpoint: cannot open %s", path);
@@ -730,6 +759,7 @@ int pt_load_checkpoint(pt_handle h, float *device_buffer, const char *path)
 int pt_ray_count(pt_handle h, uint64_t *out)
 {
     if (!h || !out) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     unsigned long long v = 0;
     PT_HIP(h, hipMemcpyAsync(&v, h->d_ray_counter, sizeof v, hipMemcpyDeviceToHost, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -740,6 +770,7 @@ int pt_ray_count(pt_handle h, uint64_t *out)
 int pt_reset_counters(pt_handle h)
 {
     if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     PT_HIP(h, hipMemsetAsync(h->d_ray_counter, 0, sizeof(unsigned long long), h->stream));
     return PT_OK;
 }
@@ -747,6 +778,7 @@ int pt_reset_counters(pt_handle h)
 int pt_last_kernel_ms(pt_handle h, float *ms)
 {
     if (!h || !ms) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     if (!h->timed) return fail(h, PT_ERR_STATE, "pt_last_kernel_ms: nothing was launched yet");
     PT_HIP(h, hipEventSynchronize(h->ev_stop));
     PT_HIP(h, hipEventElapsedTime(ms, h->ev_start, h->ev_stop));
@@ -758,6 +790,7 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
                    uint64_t *ray_count)
 {
     if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     if (!h->scene_ready) return fail(h, PT_ERR_STATE, "pt_debug_trace before pt_init_scene");
     if (x0 >= x1 || y0 >= y1 || x1 > h->camera.width || y1 > h->camera.height)
         return fail(h, PT_ERR_INVALID, "pt_debug_trace: bad rectangle [%u,%u)x[%u,%u)", x0, x1, y0, y1);
@@ -795,7 +828,7 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
         p.buffer = nullptr;
         p.ray_counter = d_cnt;
         p.hit_ids = d_hits; p.path_rad = d_rad; p.pixel_rgb = d_rgb;
-        const bool tiled = p.scene.n_prims > kMaxResidentSpheres;
+        const bool tiled = scene_streams(p.scene);
         if (h->integrator == PT_INTEGRATOR_NEE_MIS)
             DBG_HIP(launch_render_nee(p, div_up(x1 - x0, 16), p.band_rows / 16, tiled, true, h->stream));
         else
@@ -823,6 +856,7 @@ cleanup:
 int pt_selftest_eval(pt_handle h, int op, const float *a, const float *b, float *out, uint64_t n)
 {
     if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     if (op < 0 || op > 4 || !a || !out || (op == 2 && !b)) return fail(h, PT_ERR_INVALID, "pt_selftest_eval: bad arguments");
     if (n == 0) return PT_OK;
     float *da = nullptr, *db = nullptr, *dout = nullptr;
@@ -850,6 +884,7 @@ done:
 int pt_selftest_exhaustive(pt_handle h, int op, uint64_t *mismatches)
 {
     if (!h || !mismatches) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
     if (op < 0 || op > 2) return fail(h, PT_ERR_INVALID, "pt_selftest_exhaustive: op must be 0, 1 or 2");
     unsigned long long *d = nullptr, v = 0;
     int rc = PT_OK;

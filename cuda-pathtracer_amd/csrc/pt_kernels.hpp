@@ -12,6 +12,9 @@ constexpr uint32_t kTileSpheres = 1024;
 // Scenes up to this many spheres are staged in LDS once per workgroup
 // (32 B per sphere -> 16 KiB at the limit).
 constexpr uint32_t kMaxResidentSpheres = 512;
+// ... and only while spheres, materials and lights together stay below this many bytes of LDS
+// (a scene may carry far more materials than spheres).
+constexpr size_t kMaxResidentBytes = 24 * 1024;
 // Scenes with more spheres than this get a sphere BVH (pt_bvh.cpp).  Measured at 1080p on clouds of
 // small spheres in the demo room (tools/bvh_crossover.py): the scan from LDS wins up to ~110
 // spheres (2.5 vs 2.9 ms per iteration), the BVH from ~170 (3.3 vs 3.4 ms; 3.5 vs 4.8 ms at 260).

@@ -112,6 +112,40 @@ def test_matches_oracle_on_seeded_random_scenes(pt, O, torch_cuda):
         tr.Release()
 
 
+def test_scene_with_more_materials_than_lds_holds(pt, O, torch_cuda):
+    """40 spheres but 3000 materials (60 KB): the scene cannot be staged whole in LDS, so it must
+    take the streaming path (materials read from device memory) -- every kernel variant and the
+    NEE integrator, bit-exact against the oracle."""
+    from test_oracle_golden import _random_scene
+    rng = np.random.default_rng(7)
+    mats4, sph, lights = _random_scene(rng, O, 40)
+    mats = np.zeros(3000, O.MATERIAL_DTYPE)
+    mats["color"] = rng.uniform(0.2, 0.95, (3000, 3)).astype(np.float32)
+    mats["type"] = rng.integers(0, 3, 3000)
+    mats["coef"] = np.where(mats["type"] == 2, 1.4, 0.8).astype(np.float32)
+    sph["material_id"] = rng.integers(0, 3000, 40)
+    cam = pt.Camera([0, 45, 79.5], [0, 35, 0], [0, 1, 0], 48, 32, 0, 0, 50.0)
+    ref_img, _, _, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, 11, 8, n_iterations=3)
+    for variant in (pt.VARIANT_AUTO, 0, 1, pt.VARIANT_WAVEFRONT):
+        tr = pt.Pathtracer(cam, 8, 11)
+        tr.Init(mats, sph, lights)
+        tr.SetKernelVariant(variant)
+        tr.ResetCounters()
+        buf = render(torch_cuda, tr, 1, 3)
+        assert buf.cpu().numpy().tobytes() == ref_img.tobytes(), variant
+        assert tr.RayCount() == ref_rays
+        tr.Release()
+    tr = pt.Pathtracer(cam, 8, 11)
+    tr.Init(mats, sph, lights)
+    tr.SetIntegrator(pt.INTEGRATOR_NEE_MIS)
+    nee_ref, _, _, nee_rays = O.oracle_render(cam.pod, mats, sph, lights, 11, 8, n_iterations=2, integrator=1)
+    tr.ResetCounters()
+    buf = render(torch_cuda, tr, 1, 2)
+    assert buf.cpu().numpy().tobytes() == nee_ref.tobytes()
+    assert tr.RayCount() == nee_rays
+    tr.Release()
+
+
 def test_debug_trace_sub_rectangle(pt, torch_cuda):
     g = load_golden("demo_64x64_d4_it1")
     tr = make_tracer(pt, g)
