@@ -26,11 +26,12 @@ lib: $(PKG)/libptmi.so
 $(PKG)/libptmi.so: $(SRCS) $(HDRS) Makefile
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
 
-# Same library with the BVH traversal counters compiled in (pt_accel_stats); measurement only.
+# Same library with the BVH traversal counters (pt_accel_stats) and the megakernel's divergence
+# counters (pt_lane_stats) compiled in; measurement only.
 stats: tools/stats/libptmi.so
 tools/stats/libptmi.so: $(SRCS) $(HDRS) Makefile
 	mkdir -p tools/stats
-	$(HIPCC) $(HIPFLAGS) -DPT_BVH_STATS -shared -o $@ $(SRCS)
+	$(HIPCC) $(HIPFLAGS) -DPT_BVH_STATS -DPT_LANE_STATS -shared -o $@ $(SRCS)
 
 oracle:
 	$(MAKE) -C oracle all

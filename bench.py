@@ -121,8 +121,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="demo1080", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=-1,
-                    help="kernel variant (-1 auto: wavefront for BVH scenes, else 0; 0 regeneration megakernel, "
-                         "1 classic megakernel, 100 wavefront)")
+                    help="kernel variant (-1 auto: wavefront for BVH scenes, work-stealing megakernel for scenes "
+                         "staged in LDS; 0 regeneration megakernel, 1 classic megakernel, 100 wavefront, "
+                         "500 work-stealing megakernel)")
     ap.add_argument("--accel", default="auto", choices=["auto", "brute"],
                     help="scenes above 192 spheres: sphere BVH (auto) or the reference's linear scan (brute)")
     ap.add_argument("--integrator", default="path", choices=["path", "nee"],
@@ -175,7 +176,9 @@ def main():
     tr.SetIntegrator(pt.INTEGRATOR_NEE_MIS if args.integrator == "nee" else pt.INTEGRATOR_PATH)
     bvh = args.accel == "auto" and tr.AccelNodes() > 0
     # what PT_VARIANT_AUTO resolves to (pt_set_kernel_variant in include/ptmi.h)
-    eff_variant = args.variant if args.variant >= 0 else (100 if bvh and args.integrator == "path" else 0)
+    resident = len(sph) <= 512   # staged whole in LDS: the work-stealing megakernel applies
+    eff_variant = args.variant if args.variant >= 0 else (
+        (100 if bvh else (500 if resident else 0)) if args.integrator == "path" else 0)
     tr.SetStream(torch.cuda.current_stream().cuda_stream)
     if grouped:
         tr.SetAccumMode(pt.ACCUM_SUM)

@@ -39,7 +39,7 @@ POINT_LIGHT, AREA_LIGHT = 0, 1
 ACCUM_RUNNING_MEAN, ACCUM_SUM = 0, 1
 HIT_MISS, HIT_NOT_TRACED = -1, -2
 SCENE_DEMO, SCENE_SYNTH10K, SCENE_MIXED = 0, 1, 2
-VARIANT_AUTO, VARIANT_REGENERATION, VARIANT_CLASSIC, VARIANT_WAVEFRONT = -1, 0, 1, 100
+VARIANT_AUTO, VARIANT_REGENERATION, VARIANT_CLASSIC, VARIANT_WAVEFRONT, VARIANT_STEALING = -1, 0, 1, 100, 500
 ACCEL_AUTO, ACCEL_BRUTE_FORCE = 0, 1
 INTEGRATOR_PATH, INTEGRATOR_NEE_MIS = 0, 1
 PT_OK, PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_DEVICE, PT_ERR_NOMEM = 0, -1, -2, -3, -4
@@ -71,6 +71,7 @@ ABI = [
     ("pt_accel_nodes", _u32, [_vp]),
     ("pt_set_accel_budget", _i32, [_vp, _u32]),
     ("pt_accel_stats", _i32, [_vp, _pu64]),
+    ("pt_lane_stats", _i32, [_vp, _pu64]),
     ("pt_debug_build_bvh", _i32, [_vp, _u32, _pu32, _vp, _vp, _vp]),
     ("pt_last_kernel_ms", _i32, [_vp, _pf]),
     ("pt_read_image", _i32, [_vp, _vp, _vp]),

@@ -42,6 +42,9 @@ struct pt_context {
     int accel;            // PT_ACCEL_*
     // misc device state
     unsigned long long *d_ray_counter;
+    float *d_steal;            // scratch of the work-stealing megakernel, allocated on first use
+    size_t steal_capacity;     // in pixels
+    bool steal;                // work stealing inside the wave where the kernel supports it
     float *d_internal_buffer; // frame buffer owned by the library when the caller passes host memory
     hipEvent_t ev_start, ev_stop;
     bool timed;
@@ -153,6 +156,9 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->d_bvh = nullptr;
     h->accel = PT_ACCEL_AUTO;
     h->d_ray_counter = nullptr;
+    h->d_steal = nullptr;
+    h->steal_capacity = 0;
+    h->steal = true;           // PT_VARIANT_AUTO
     h->d_internal_buffer = nullptr;
     h->ev_start = h->ev_stop = nullptr;
     h->timed = false;
@@ -259,6 +265,7 @@ int pt_destroy(pt_handle h)
     free_scene(h);
     free_wavefront(h);
     if (h->d_ray_counter) (void)hipFree(h->d_ray_counter);
+    if (h->d_steal) (void)hipFree(h->d_steal);
     if (h->d_internal_buffer) (void)hipFree(h->d_internal_buffer);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
@@ -454,14 +461,26 @@ int pt_accel_stats(pt_handle h, uint64_t out[32])
     return PT_OK;
 }
 
+int pt_lane_stats(pt_handle h, uint64_t out[64])
+{
+    if (!h || !out) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    unsigned long long v[64];
+    PT_HIP(h, read_lane_stats(v));
+    for (int i = 0; i < 64; ++i) out[i] = (uint64_t)v[i];
+    return PT_OK;
+}
+
 int pt_set_kernel_variant(pt_handle h, int variant)
 {
     if (!h) return PT_ERR_INVALID;
     h->wavefront = false;
     h->auto_variant = false;
     h->small_scene_opts = 1;
+    h->steal = false;
     h->wf_dynamic_fetch = 44;
-    if (variant == PT_VARIANT_AUTO) { h->auto_variant = true; h->regen_min_idle = 1; }
+    if (variant == PT_VARIANT_AUTO) { h->auto_variant = true; h->regen_min_idle = 1; h->steal = true; }
     else if (variant >= PT_VARIANT_WAVEFRONT && variant <= PT_VARIANT_WAVEFRONT + 64) {
         // +1: static assignment of paths to lanes; +2..+64: refill threshold of the dynamic fetch (A/B)
         h->wavefront = true;
@@ -469,6 +488,8 @@ int pt_set_kernel_variant(pt_handle h, int variant)
         h->wf_dynamic_fetch = k == 0 ? 44 : (k == 1 ? 0 : k);
     }
     else if (variant >= 300 && variant <= 301) { h->regen_min_idle = 1; h->small_scene_opts = variant - 300; } // experiments
+    else if (variant == PT_VARIANT_STEALING) { h->regen_min_idle = 1; h->steal = true; }
+    else if (variant == PT_VARIANT_STEALING + 1) { h->regen_min_idle = 1; h->small_scene_opts = 0; h->steal = true; } // experiment: no ring
     else if (variant == 0) h->regen_min_idle = 1;
     else if (variant == 1) h->regen_min_idle = 64;
     else if (variant >= 2 && variant <= 64) h->regen_min_idle = variant; // experimental: idle-lane threshold
@@ -633,6 +654,20 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
     }
     const bool tiled = scene_streams(p.scene);
     if (grid_y > 0) {
+        if (h->steal && !tiled && p.scene.bvh.n_nodes == 0 && h->integrator == PT_INTEGRATOR_PATH && n_iterations >= 4) {
+            const size_t pixels = (size_t)p.cam.width * p.cam.height;
+            if (pixels > h->steal_capacity) {
+                PT_HIP(h, hipStreamSynchronize(h->stream));
+                if (h->d_steal) (void)hipFree(h->d_steal);
+                h->d_steal = nullptr; h->steal_capacity = 0;
+                // without the scratch the launch simply does not steal
+                if (hipMalloc((void **)&h->d_steal, pixels * kStealSlots * 3 * sizeof(float)) == hipSuccess)
+                    h->steal_capacity = pixels;
+                else
+                    (void)hipGetLastError();
+            }
+            p.steal_scratch = h->d_steal;
+        }
         PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
         if (h->integrator == PT_INTEGRATOR_NEE_MIS)
             PT_HIP(h, launch_render_nee(p, div_up(p.cam.width, 16), grid_y, tiled, false, h->stream));

@@ -19,6 +19,22 @@ namespace ptmi {
 
 #define PT_DEV __device__ __forceinline__
 
+// Measurement builds (-DPT_LANE_STATS, tools/stats): PT_LS(i) counts, per code site i, how often a
+// wave executes the site and with how many active lanes.  Empty in the product build.
+#ifdef PT_LANE_STATS
+static __device__ unsigned long long g_lane_stats[2 * 32];
+#define PT_LS(i)                                                                                       \
+    do {                                                                                               \
+        const unsigned long long m_ = __ballot(1);                                                     \
+        if ((int)__lane_id() == __ffsll(m_) - 1) {                                                     \
+            atomicAdd(&g_lane_stats[2 * (i)], 1ull);                                                   \
+            atomicAdd(&g_lane_stats[2 * (i) + 1], (unsigned long long)__popcll(m_));                   \
+        }                                                                                              \
+    } while (0)
+#else
+#define PT_LS(i) ((void)0)
+#endif
+
 // ---- correctly rounded sqrt, 1/x and a/b ------------------------------------------------------
 // hipcc's IEEE expansions of sqrtf and '/' carry denormal pre-scaling, class checks and
 // div_scale/div_fixup steps made of half-rate compare/select instructions (~55 and ~40 issue
@@ -253,7 +269,9 @@ PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &
     float root_arg, cosI = 0.f, eta = 1.f;
     bool tir = false;
     V3 ret = mk(0.f, 0.f, 0.f);
+    PT_LS(10);
     if (is_g) {
+        PT_LS(11);
         // reflectance(), globals.h:117-121
         eta = outside ? q : coef;
         cosI = -(dot(nnor, wo));
@@ -261,6 +279,7 @@ PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &
         tir = sinT2 > 1.0f;
         root_arg = tir ? 1.f : 1.0f - sinT2;   // total internal reflection: the root is not used
     } else {
+        PT_LS(12);
         // montecarlo.h:115-117, 129-130
         float theta = (r2 || r3) ? off - q : off + q;
         theta *= PT_M_PI / 4.f;
@@ -279,6 +298,7 @@ PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &
     V3 vec;              // direction before normalisation
     bool do_reflect = is_s;
     if (is_g) {
+        PT_LS(13);
         // reflectance(), globals.h:122-125
         const float cosT = root;
         const float x = pt_div(cosI - coef * cosT, cosI + coef * cosT);
@@ -289,6 +309,7 @@ PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &
         // Refract, globals.h:111-115, before its Normalize(): cost == -cosI, sqrt(cos2t) == cosT
         vec = wo * eta - nnor * (eta * (-cosI) + cosT);
     } else {
+        PT_LS(14);
         // RotateByNormal, montecarlo.h:120-124, before its Normalize()
         ret.z = root;
         const V3 w = n;
@@ -298,8 +319,8 @@ PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &
     }
 
     // ---- normalisation (diffuse, refraction) or mirror direction (specular, Fresnel reflection)
-    if (do_reflect) wi = reflect(wo, nnor);
-    else            wi = normalize(vec);
+    if (do_reflect) { PT_LS(15); wi = reflect(wo, nnor); }
+    else            { PT_LS(16); wi = normalize(vec); }
 
     V3 f = mk(0.f, 0.f, 0.f);
     if (is_d) {
@@ -327,7 +348,9 @@ PT_DEV void sphere_test(float4 s, int index, V3 o, V3 d, float &tmax, int &best)
     const float opx = s.x - o.x, opy = s.y - o.y, opz = s.z - o.z;
     const float b = opx * d.x + opy * d.y + opz * d.z;
     const float det = b * b - (opx * opx + opy * opy + opz * opz) + s.w;
+    PT_LS(2);
     if (!(det < 0.f)) {
+        PT_LS(3);
         const float sq = pt_sqrt(det);
         float t = b - sq;
         if (!(t > PT_EPSILON)) t = b + sq;

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
         if (RING) {
             if (__any(want && cons == gen * 4u)) {
                 if (!done && gen < p.n_iterations && gen * 4u - cons <= 4u) {
+                    PT_LS(0);
                     V3 dirs[4];
                     camera_rays4(p.cam, x, y, pix, p.first_iteration + gen, k0, k1, dirs);
                     const uint32_t base = (gen & 1u) * 4u;
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
             }
         }
         if (want) {
+            PT_LS(1);
             o = cam_pos;
             if (RING) {
                 const float *slot = ring + ((cons & 7u) * 3u) * kBlockThreads + tid;
@@ -124,7 +126,9 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
         int best;
         intersect_scene<TILED, BVH>(p.scene, sc, lds_raw, tid, alive, o, d, tmax, best);
 
+        PT_LS(4);
         if (alive) {
+            PT_LS(17);
             ++nrays;
             if (RECORD) {
                 if (p.hit_ids)
@@ -142,9 +146,11 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
                         pr[0] = L.x; pr[1] = L.y; pr[2] = L.z;
                     }
                 }
+                PT_LS(18);
                 c = c + L;
                 alive = false;
                 if (++sub == 4) {
+                    PT_LS(19);
                     V3 cpix;
                     acc = accumulate_pixel(acc, c, it, p.accum_mode, &cpix);
                     if (RECORD) {
@@ -161,6 +167,206 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
         }
     }
 
+    if (valid && p.buffer && p.n_iterations) {
+        float *px = p.buffer + (size_t)pix * 3;
+        px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
+    }
+    const uint32_t total = wave_sum(nrays);
+    if (lane == 0 && p.ray_counter && total) atomicAdd(p.ray_counter, (unsigned long long)total);
+}
+
+// ---- megakernel with work stealing inside the wave ---------------------------------------------------
+// render_kernel gives every lane one pixel for the whole launch.  The pixels of a wave need
+// different numbers of bounces, so lanes finish at different times and wait for the slowest one:
+// at 1080p with 64 iterations 11 % of the lanes have no ray in the average loop pass (measured with
+// the divergence counters, pt_lane_stats).  Here a lane without work of its own takes over a whole
+// pixel-iteration (the four paths of one pixel in one iteration) from the lane with the most
+// iterations left:
+//   - always the LAST iteration the victim has not started (and has no camera rays for yet), so
+//     the victim's own iterations stay a prefix 1..E of the range and are folded into the running
+//     mean as they complete, exactly as before;
+//   - the thief traces the four paths in order, which gives the same c = ((0+L0)+L1)+L2)+L3, and
+//     leaves it in a per-pixel scratch slot in device memory (the stolen iterations are rare: a
+//     few per lane and launch);
+//   - when the wave has no work left, every lane folds the stolen iterations E..end of ITS pixel
+//     from the scratch slots in ascending order: the accumulation order of the reference
+//     (pathtracer.cu:104-109) is kept and the image is bit-identical.
+// At most kStealSlots iterations are taken from one pixel per launch.  Stealing costs nothing
+// until the first lane of a wave runs out of work (one wave-wide test per pass).
+template <bool RING>
+__global__ __launch_bounds__(kBlockThreads) void render_steal_kernel(const RenderParams p)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const SceneView sc = stage_scene<false>(p.scene, lds_raw, tid);
+
+    const uint32_t blocks_per_band = p.band_rows >> 4;
+    const uint32_t band_local = blockIdx.y / blocks_per_band;
+    const uint32_t band = band_local * p.band_world + p.band_rank;
+    const uint32_t yb = p.y0 + band * p.band_rows + (blockIdx.y - band_local * blocks_per_band) * 16u;
+    const uint32_t wave_x0 = p.x0 + blockIdx.x * 16u + (uint32_t)((wave & 1) * 8);
+    const uint32_t wave_y0 = yb + (uint32_t)((wave >> 1) * 8);
+    const uint32_t x = wave_x0 + (uint32_t)(lane & 7), y = wave_y0 + (uint32_t)(lane >> 3);
+    const bool valid = x < p.x1 && y < p.y1;
+    const uint32_t pix = y * p.cam.width + x;
+
+    const V3 cam_pos = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+    const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
+    const int mb = p.max_bounces;
+    const uint32_t first = p.first_iteration;
+    const uint32_t it_end = p.first_iteration + p.n_iterations;
+
+    // ---- this lane's pixel -------------------------------------------------------------------------
+    uint32_t it = first;                     // next own iteration to start
+    uint32_t own_end = valid ? it_end : first;   // own iterations are [first, own_end); thieves lower it
+    V3 acc = mk(0.f, 0.f, 0.f);
+    if (valid && !p.overwrite && p.buffer) {
+        const float *px = p.buffer + (size_t)pix * 3;
+        acc = mk(px[0], px[1], px[2]);
+    }
+    // ---- the pixel-iteration in hand (own or stolen) and its current path --------------------------------
+    bool has_task = false, alive = false;
+    uint32_t tpix = pix, tit = first;
+    // -1: the lane's own pixel; else the lane (of this wave) the iteration was taken from, + 64 when
+    // its camera rays sit in that lane's ring
+    int t_from = -1;
+    int sub = 0;
+    V3 c = mk(0.f, 0.f, 0.f);
+    V3 o = cam_pos, d = mk(0.f, 0.f, 1.f), T = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
+    int b = 0;
+    uint32_t nrays = 0;
+    bool stealing = p.steal_scratch != nullptr;   // wave-uniform; cleared once nothing is left to steal
+
+    // camera-ray ring of the lane's OWN iterations, see render_kernel
+    float *ring = reinterpret_cast<float *>(lds_raw + scene_lds_bytes_dev(p.scene));
+    uint32_t gen = 0;    // own pixel-iterations generated into the ring so far
+    uint32_t cons = 0;   // own paths started so far
+
+    if (it < own_end) { has_task = true; ++it; }   // the first own iteration (tpix, tit, t_from are set for it)
+
+    for (;;) {
+        // ---- a lane that has finished its own iterations takes the last unstarted one of the lane
+        //      with the most left ----------------------------------------------------------------------------
+        if (stealing && __any(!has_task)) {
+            PT_LS(20);
+            for (;;) {
+                // iterations this lane could give away: the ones it has not started
+                const uint32_t spare = (own_end > it && it_end - own_end < kStealSlots) ? own_end - it : 0u;
+                uint32_t key = (spare << 6) | (uint32_t)lane;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint32_t other = (uint32_t)__shfl_xor((int)key, off, 64);
+                    key = other > key ? other : key;
+                }
+                key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+                if ((key >> 6) == 0u) { stealing = false; break; }
+                const unsigned long long idle = __ballot(!has_task);
+                if (!idle) break;
+                const int thief = __ffsll(idle) - 1;
+                const int victim = (int)(key & 63u);
+                const uint32_t v_it = (uint32_t)__builtin_amdgcn_readlane((int)own_end, victim) - 1u;
+                const uint32_t v_pix = (uint32_t)__builtin_amdgcn_readlane((int)pix, victim);
+                // the victim's ring already holds the camera rays of its next iterations; it will not
+                // write to that slot again (it generates no iteration at or beyond own_end)
+                const uint32_t v_gen = (uint32_t)__builtin_amdgcn_readlane((int)gen, victim);
+                if (lane == victim) own_end = v_it;
+                if (lane == thief) {
+                    PT_LS(21);
+                    has_task = true;
+                    tpix = v_pix; tit = v_it;
+                    t_from = victim + ((RING && v_it < first + v_gen) ? 64 : 0);
+                    sub = 0;
+                    c = mk(0.f, 0.f, 0.f);
+                }
+            }
+        }
+
+        // ---- next path of the pixel-iteration ------------------------------------------------------------------
+        const bool want = has_task && !alive;
+        if (RING) {
+            if (__any(want && t_from < 0 && cons == gen * 4u)) {
+                if (first + gen < own_end && gen * 4u - cons <= 4u) {
+                    V3 dirs[4];
+                    camera_rays4(p.cam, x, y, pix, first + gen, k0, k1, dirs);
+                    const uint32_t base = (gen & 1u) * 4u;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        float *slot = ring + ((base + s) * 3u) * kBlockThreads + tid;
+                        slot[0] = dirs[s].x; slot[kBlockThreads] = dirs[s].y; slot[2 * kBlockThreads] = dirs[s].z;
+                    }
+                    ++gen;
+                }
+            }
+        }
+        if (want) {
+            o = cam_pos;
+            if (RING && t_from < 0) {
+                const float *slot = ring + ((cons & 7u) * 3u) * kBlockThreads + tid;
+                d = mk(slot[0], slot[kBlockThreads], slot[2 * kBlockThreads]);
+                ++cons;
+            } else if (RING && t_from >= 64) {
+                const float *slot = ring + ((((tit - first) & 1u) * 4u + (uint32_t)sub) * 3u) * kBlockThreads +
+                                    (tid - lane + (t_from - 64));
+                d = mk(slot[0], slot[kBlockThreads], slot[2 * kBlockThreads]);
+            } else {
+                const int from = t_from < 0 ? lane : t_from;
+                d = camera_ray(p.cam, wave_x0 + (uint32_t)(from & 7), wave_y0 + (uint32_t)(from >> 3), tpix, tit, sub,
+                               k0, k1);
+            }
+            T = mk(1.f, 1.f, 1.f);
+            L = mk(0.f, 0.f, 0.f);
+            b = 0;
+            alive = true;
+        }
+        if (!__any(alive)) break;
+
+        float tmax;
+        int best;
+        intersect_scene<false, false>(p.scene, sc, lds_raw, tid, alive, o, d, tmax, best);
+
+        PT_LS(4);
+        if (alive) {
+            PT_LS(17);
+            ++nrays;
+            bool end = true;
+            if (best >= 0)
+                end = shade_bounce(sc, sc.sph[best], best, tmax, tpix, tit, k0, k1, mb, o, d, T, L, b);
+            if (end) {
+                c = c + L;
+                alive = false;
+                if (++sub == 4) {
+                    if (t_from >= 0) {
+                        float *slot = p.steal_scratch + ((size_t)tpix * kStealSlots + (it_end - 1u - tit)) * 3;
+                        slot[0] = c.x; slot[1] = c.y; slot[2] = c.z;
+                    } else {
+                        acc = accumulate_pixel(acc, c, tit, p.accum_mode);
+                    }
+                    // next own iteration, if any is left (a thief has none: it only steals once it == own_end)
+                    has_task = it < own_end;
+                    t_from = -1;
+                    tpix = pix; tit = it;
+                    it += has_task ? 1u : 0u;
+                    sub = 0;
+                    c = mk(0.f, 0.f, 0.f);
+                }
+            }
+        }
+    }
+
+    // ---- the iterations other lanes of this wave rendered for this pixel, in order --------------------------------
+    if (own_end < it_end && valid) {
+        __threadfence_block();   // their results were stored by this same wave
+        for (uint32_t k = own_end; k < it_end; ++k) {
+            const float *slot = p.steal_scratch + ((size_t)pix * kStealSlots + (it_end - 1u - k)) * 3;
+            // read past the vector cache: the line may have been cached before a thief wrote to it
+            const V3 cs = mk(__hip_atomic_load(slot + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                             __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                             __hip_atomic_load(slot + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            acc = accumulate_pixel(acc, cs, k, p.accum_mode);
+        }
+    }
     if (valid && p.buffer && p.n_iterations) {
         float *px = p.buffer + (size_t)pix * 3;
         px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
@@ -232,6 +438,21 @@ hipError_t launch_selftest_exhaustive(int op, unsigned long long *mismatches, hi
     return hipGetLastError();
 }
 
+// Lane statistics of the megakernels in this file (measurement builds only): reads and clears the
+// 32 (executions, active lanes) pairs; all zero in the product build.
+hipError_t read_lane_stats(unsigned long long out[64])
+{
+#ifdef PT_LANE_STATS
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lane_stats), 64 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    static const unsigned long long zeros[64] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stats), zeros, sizeof zeros);
+#else
+    for (int i = 0; i < 64; ++i) out[i] = 0;
+    return hipSuccess;
+#endif
+}
+
 size_t scene_lds_bytes(const SceneParams &s, bool tiled)
 {
     if (tiled) return (size_t)kTileSpheres * sizeof(float4);
@@ -255,6 +476,13 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y
     // switch it off).  A branch-free variant of the scan was measured 3.5 % slower and dropped.
     const bool ring = !tiled && p.scene.n_prims <= kMaxRingSpheres && (p.small_scene_opts & 1);
     const bool bvh = p.scene.bvh.n_nodes > 0;   // BVH kernels read the scene from global memory
+    // Work stealing inside the wave: scenes staged in LDS, plain renders, regeneration on
+    if (p.steal_scratch && !tiled && !bvh && !record && p.regen_min_idle <= 1) {
+        const size_t lds = render_lds_bytes(p.scene, false, ring);
+        if (ring) hipLaunchKernelGGL((render_steal_kernel<true>), grid, block, lds, stream, p);
+        else      hipLaunchKernelGGL((render_steal_kernel<false>), grid, block, lds, stream, p);
+        return hipGetLastError();
+    }
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : render_lds_bytes(p.scene, tiled, ring);
 #define PT_LAUNCH(T, R, G, B) hipLaunchKernelGGL((render_kernel<T, R, G, B>), grid, block, lds, stream, p)
     if (bvh) {

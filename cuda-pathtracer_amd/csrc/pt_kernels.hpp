@@ -21,6 +21,8 @@ constexpr size_t kMaxResidentBytes = 24 * 1024;
 constexpr uint32_t kBvhMinSpheres = 192;
 // Scenes up to this many spheres also keep a per-lane ring of pre-generated camera rays in LDS.
 constexpr uint32_t kMaxRingSpheres = 24;
+// Work stealing inside the wave: iterations per pixel and launch that other lanes may take over.
+constexpr uint32_t kStealSlots = 8;
 
 // What Camera::GenerateRay reads (camera.h:66-72).
 struct CameraParams {
@@ -71,6 +73,9 @@ struct RenderParams {
     int overwrite;            // 1: start from zero instead of reading the buffer
     int regen_min_idle;       // 1..64, idle lanes needed before a wave starts new paths
     int small_scene_opts;     // bit 0: camera-ray ring (scenes <= kMaxRingSpheres)
+    // work stealing inside the wave (render_steal_kernel): [width*height][kStealSlots][3] floats of
+    // scratch for the pixel-iterations rendered by another lane than the pixel's; NULL: no stealing
+    float *steal_scratch;
     // outputs
     float *buffer;                     // width*height*3, may be NULL (debug trace)
     unsigned long long *ray_counter;   // += number of Intersect calls
@@ -86,6 +91,8 @@ inline size_t bvh_stack_lds_bytes(const BvhParams &b) { return (size_t)(b.depth 
 // grid_x x grid_y workgroups of 256 threads, each a 16x16 pixel tile.
 hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled,
                          bool record, hipStream_t stream);
+
+hipError_t read_lane_stats(unsigned long long out[64]);
 
 // The opt-in NEE + MIS integrator (pt_nee.hip); same launch geometry.
 hipError_t launch_render_nee(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled, bool record,

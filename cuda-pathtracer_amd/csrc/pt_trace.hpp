@@ -431,7 +431,9 @@ PT_DEV bool shade_bounce(const SceneView &sc, float4 s, int best, float t, uint3
     const int light_id = __float_as_int(a.z);
 
     // emission on every light hit: pathtracer.cu:134-137, Light::L light.h:43-45
+    PT_LS(5);
     if (light_id > -1) {
+        PT_LS(6);
         const float4 li = sc.light[light_id];
         const V3 le = dot(n, -wo) > 0.f ? mk(li.x, li.y, li.z) : mk(0.f, 0.f, 0.f);
         L = L + T * le;
@@ -446,11 +448,13 @@ PT_DEV bool shade_bounce(const SceneView &sc, float4 s, int best, float t, uint3
     const V3 f = sample_material(mtype, mk(m.x, m.y, m.z), m.w, wo, wi, pdf, n, u01(r[0]), u01(r[1]));
     // pathtracer.cu:146-161
     if ((f.x == 0.f && f.y == 0.f && f.z == 0.f) || pdf == 0.f) return true;
+    PT_LS(7);
     T = T * vdiv(f * __builtin_fabsf(dot(wi, n)), pdf);
     o = P;
     d = wi;
     bool end = false;
     if (b > 3) {
+        PT_LS(8);
         const float gb = T.y > T.z ? T.y : T.z;   // Color::Max, geometry.h:474
         const float mx = T.x > gb ? T.x : gb;
         const float q = .5f < mx ? .5f : mx;      // min macro, globals.h:66

@@ -146,7 +146,12 @@ int pt_reset_counters(pt_handle h);
 /* Kernel variant; results are bit-identical in all of them.
  *   PT_VARIANT_AUTO (default): PT_VARIANT_WAVEFRONT for scenes rendered through the sphere BVH
  *     (when no row bands are set and the integrator is PT_INTEGRATOR_PATH), else
- *     PT_VARIANT_REGENERATION
+ *     PT_VARIANT_STEALING
+ *   PT_VARIANT_STEALING: PT_VARIANT_REGENERATION, and a lane that has finished its pixel takes
+ *     whole pixel-iterations over from the lane of its wave with the most left.  Applies to scenes
+ *     small enough to be staged in LDS (up to 512 spheres, no BVH) with PT_INTEGRATOR_PATH and
+ *     launches of at least 4 iterations; allocates 96 bytes of scratch per pixel on first use
+ *     (199 MB at 1080p); everything else, or a failed allocation, runs PT_VARIANT_REGENERATION
  *   PT_VARIANT_REGENERATION: megakernel, persistent lanes with path regeneration
  *   PT_VARIANT_CLASSIC: megakernel, a wave starts new paths only when all its lanes are idle
  *   2..64: megakernel, regeneration once that many lanes of a wave are idle (experiments)
@@ -154,7 +159,8 @@ int pt_reset_counters(pt_handle h);
  *     (allocates about 4 GiB of queues on first use; no row bands).  BVH scenes: persistent
  *     waves that refill idle lanes from the queue while the other lanes keep traversing;
  *     PT_VARIANT_WAVEFRONT + 1 switches that off, + 2..64 sets the refill threshold (experiments) */
-enum { PT_VARIANT_AUTO = -1, PT_VARIANT_REGENERATION = 0, PT_VARIANT_CLASSIC = 1, PT_VARIANT_WAVEFRONT = 100 };
+enum { PT_VARIANT_AUTO = -1, PT_VARIANT_REGENERATION = 0, PT_VARIANT_CLASSIC = 1, PT_VARIANT_WAVEFRONT = 100,
+       PT_VARIANT_STEALING = 500 };
 int pt_set_kernel_variant(pt_handle h, int variant);
 /* Integrator.
  *   PT_INTEGRATOR_PATH (default): Trace as the reference runs it, pathtracer.cu:112-170.
@@ -198,6 +204,14 @@ int pt_debug_build_bvh(const pt_sphere *spheres, uint32_t n_spheres, uint32_t co
  *   its slowest lane is done)  [6] wave-level traversals  [7] rays with a direction longer than 1
  *   [8 + k] rays whose visit count n satisfies 2^k <= n + 1 < 2^(k+1) */
 int pt_accel_stats(pt_handle h, uint64_t out[32]);
+/* Divergence counters of the megakernel since the last call (only libraries built with
+ * -DPT_LANE_STATS count, others return zeros): for code site i, out[2*i] = times a wave executed
+ * the site, out[2*i+1] = lanes active in those executions.  Sites: 0 camera-ray ring refill,
+ * 1 path start, 2 sphere test, 3 its square-root part, 4 loop pass, 5 bounce shading, 6 emission,
+ * 7 throughput update, 8 Russian roulette, 10 BSDF sample, 11/13 its glass-only parts, 12/14 its
+ * diffuse-only parts, 15 mirror direction, 16 normalised direction, 17 lanes with a ray in a pass,
+ * 18 path end, 19 pixel-iteration end.  Has no counterpart in the reference (measurement only). */
+int pt_lane_stats(pt_handle h, uint64_t out[64]);
 /* HIP-event time of the last pt_run/pt_run_n launch in milliseconds (waits for it). */
 int pt_last_kernel_ms(pt_handle h, float *ms);
 

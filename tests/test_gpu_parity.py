@@ -214,6 +214,60 @@ def test_kernel_variants_agree(pt, torch_cuda):
     assert imgs[0] == imgs[1] == imgs[2] == imgs[3] == g["image"].tobytes()
 
 
+def test_work_stealing_variant_is_bit_exact(pt, O, torch_cuda):
+    """PT_VARIANT_STEALING (lanes take pixel-iterations over from other lanes of their wave)
+    against the plain megakernel and the oracle: image bytes and ray counts, with and without the
+    camera-ray ring (9 / 71 spheres), image sizes that leave tiles partly outside the image,
+    continued renders, the sum buffer, row bands and more stolen iterations than scratch slots
+    allow (40 iterations of very uneven pixels)."""
+    cases = [  # scene, (w, h), depth, first iteration, iterations
+        (pt.SCENE_DEMO, (64, 64), 8, 1, 12), (pt.SCENE_DEMO, (50, 37), 8, 1, 9), (pt.SCENE_DEMO, (50, 37), 4, 3, 24),
+        (pt.SCENE_DEMO, (17, 9), 8, 1, 40), (pt.SCENE_MIXED, (48, 40), 16, 1, 8), (pt.SCENE_MIXED, (33, 21), 16, 5, 16),
+        (pt.SCENE_DEMO, (64, 64), 8, 1, 4), (pt.SCENE_DEMO, (64, 64), 8, 1, 3),
+    ]
+    for scene, (w, h), depth, first, n in cases:
+        mats, sph, lights, (eye, look, up, fov) = pt.build_scene(scene, 1)
+        cam = pt.Camera(eye, look, up, w, h, 0, 0, fov)
+        imgs, rays = {}, {}
+        for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING, pt.VARIANT_STEALING + 1, pt.VARIANT_AUTO):
+            tr = pt.Pathtracer(cam, depth, 5)
+            tr.Init(mats, sph, lights)
+            tr.SetKernelVariant(variant)
+            buf = torch_cuda.full((w * h * 3,), 0.25, dtype=torch_cuda.float32, device="cuda")
+            if first > 1:   # the running mean continues from what the earlier iterations left
+                render(torch_cuda, tr, 1, first - 1, buf=buf)
+            tr.ResetCounters()
+            tr.SetIteration(first - 1)
+            tr.RunN(buf, n)
+            torch_cuda.cuda.synchronize()
+            imgs[variant], rays[variant] = buf.cpu().numpy().tobytes(), tr.RayCount()
+            tr.Release()
+        for variant in imgs:
+            assert imgs[variant] == imgs[pt.VARIANT_REGENERATION], (scene, w, h, variant)
+            assert rays[variant] == rays[pt.VARIANT_REGENERATION]
+        if first == 1 and w * h <= 64 * 64:
+            ref, _, _, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, 5, depth, n_iterations=n)
+            assert imgs[pt.VARIANT_STEALING] == ref.tobytes(), (scene, w, h)
+            assert rays[pt.VARIANT_STEALING] == ref_rays
+    # sum buffer and row bands
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO, 1)
+    cam = pt.Camera(eye, look, up, 80, 72, 0, 0, fov)
+    out = {}
+    for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING):
+        tr = pt.Pathtracer(cam, 8, 3)
+        tr.Init(mats, sph, lights)
+        tr.SetKernelVariant(variant)
+        tr.SetAccumMode(pt.ACCUM_SUM)
+        tr.SetRowBands(16, 1, 3)
+        buf = torch_cuda.zeros(80 * 72 * 3, dtype=torch_cuda.float32, device="cuda")
+        tr.RunN(buf, 10)
+        tr.RunN(buf, 6)
+        torch_cuda.cuda.synchronize()
+        out[variant] = buf.cpu().numpy().tobytes()
+        tr.Release()
+    assert out[pt.VARIANT_STEALING] == out[pt.VARIANT_REGENERATION]
+
+
 def test_tile_split_is_bit_exact(pt, torch_cuda):
     """Row bands rendered by different instances into zero-filled buffers sum to the 1-instance image."""
     g = load_golden("demo_64x48_d8_it1-4")

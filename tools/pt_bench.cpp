@@ -58,6 +58,18 @@ int main(int argc, char **argv)
         printf("scene %d %ux%u it%u d%d v%d: wall %.3f ms kernel %.3f ms  %.3f Gbounces/s  rays %llu  hash %016llx\n",
                scene, w, h, iters, depth, variant, dt * 1e3, ms, rays / (ms * 1e-3) / 1e9,
                (unsigned long long)rays, (unsigned long long)hash);
+        uint64_t ls[64];
+        if (pt_lane_stats(hd, ls) == PT_OK && ls[8]) {
+            static const char *site[32] = {"ring refill", "path start", "sphere test", "sphere sqrt part", "loop pass",
+                "bounce shading", "emission", "throughput update", "russian roulette", "", "bsdf sample", "glass part 1",
+                "diffuse part 1", "glass part 2", "diffuse part 2", "mirror direction", "normalised direction",
+                "lanes with a ray", "path end", "pixel-iteration end", "steal attempt", "steal"};
+            printf("  lane statistics: site, wave executions, executions per loop pass, mean active lanes / 64\n");
+            for (int i = 0; i < 22; ++i)
+                if (ls[2 * i])
+                    printf("    %2d %-22s %12llu  %7.3f  %6.3f\n", i, site[i], (unsigned long long)ls[2 * i],
+                           (double)ls[2 * i] / (double)ls[8], (double)ls[2 * i + 1] / (64.0 * (double)ls[2 * i]));
+        }
         uint64_t st[32];
         if (pt_accel_stats(hd, st) == PT_OK && st[2]) {
             printf("  bvh: %.1f inner nodes + %.1f leaves per ray, %llu rays, %llu over budget, %llu long-direction\n",
