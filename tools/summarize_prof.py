@@ -41,11 +41,11 @@ def main():
     for path in sorted(glob.glob(os.path.join(base, "*", "pmc_counter_collection.csv"))):
         with open(path) as f:
             for r in csv.DictReader(f):
-                if "render_kernel" not in r["Kernel_Name"] and "wf_" not in r["Kernel_Name"]:
+                if "render_" not in r["Kernel_Name"] and "wf_" not in r["Kernel_Name"]:
                     continue
                 sums[r["Counter_Name"]] += float(r["Counter_Value"])
                 counts[r["Counter_Name"]] += 1
-                if "wf_step" in r["Kernel_Name"] or "render_kernel" in r["Kernel_Name"]:
+                if "wf_step" in r["Kernel_Name"] or "render_" in r["Kernel_Name"]:
                     kernels.add(r["Kernel_Name"])
                 meta = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size",
                                           "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r}
@@ -60,7 +60,7 @@ def main():
             n_steps = j["steps"] + j["warmup"]
     wavefront = any("wf_" in k for k in kernels)
     avg = {k: (sums[k] / n_steps if wavefront else sums[k] / counts[k]) for k in sums}
-    print(f"## PMC counters per bench step ({'sum over all wf_* launches of a step' if wavefront else 'one render_kernel launch'})\n")
+    print(f"## PMC counters per bench step ({'sum over all wf_* launches of a step' if wavefront else 'one megakernel launch'})\n")
     print("launch: " + ", ".join(f"{k}={v}" for k, v in meta.items()) + "\n")
     print("| counter | value |\n|---|---|")
     for k in sorted(avg):
