@@ -45,6 +45,9 @@ struct pt_context {
     float *d_steal;            // scratch of the work-stealing megakernel, allocated on first use
     size_t steal_capacity;     // in pixels
     bool steal;                // work stealing inside the wave where the kernel supports it
+    uint32_t *d_tickets;       // chunked launches: start-order counter + one progress word per tile
+    size_t tickets_capacity;   // in words
+    int chunks;                // 0: chosen per launch; n: iteration ranges per launch (experiments)
     float *d_internal_buffer; // frame buffer owned by the library when the caller passes host memory
     hipEvent_t ev_start, ev_stop;
     bool timed;
@@ -159,6 +162,9 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->d_steal = nullptr;
     h->steal_capacity = 0;
     h->steal = true;           // PT_VARIANT_AUTO
+    h->d_tickets = nullptr;
+    h->tickets_capacity = 0;
+    h->chunks = 0;
     h->d_internal_buffer = nullptr;
     h->ev_start = h->ev_stop = nullptr;
     h->timed = false;
@@ -266,6 +272,7 @@ int pt_destroy(pt_handle h)
     free_wavefront(h);
     if (h->d_ray_counter) (void)hipFree(h->d_ray_counter);
     if (h->d_steal) (void)hipFree(h->d_steal);
+    if (h->d_tickets) (void)hipFree(h->d_tickets);
     if (h->d_internal_buffer) (void)hipFree(h->d_internal_buffer);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
@@ -479,6 +486,7 @@ int pt_set_kernel_variant(pt_handle h, int variant)
     h->auto_variant = false;
     h->small_scene_opts = 1;
     h->steal = false;
+    h->chunks = 0;
     h->wf_dynamic_fetch = 44;
     if (variant == PT_VARIANT_AUTO) { h->auto_variant = true; h->regen_min_idle = 1; h->steal = true; }
     else if (variant >= PT_VARIANT_WAVEFRONT && variant <= PT_VARIANT_WAVEFRONT + 64) {
@@ -489,6 +497,9 @@ int pt_set_kernel_variant(pt_handle h, int variant)
     }
     else if (variant >= 300 && variant <= 301) { h->regen_min_idle = 1; h->small_scene_opts = variant - 300; } // experiments
     else if (variant == PT_VARIANT_STEALING) { h->regen_min_idle = 1; h->steal = true; }
+    else if (variant >= PT_VARIANT_STEALING + 10 && variant <= PT_VARIANT_STEALING + 26) { // experiments: iteration ranges
+        h->regen_min_idle = 1; h->steal = true; h->chunks = variant - (PT_VARIANT_STEALING + 10) + 1;
+    }
     else if (variant == PT_VARIANT_STEALING + 1) { h->regen_min_idle = 1; h->small_scene_opts = 0; h->steal = true; } // experiment: no ring
     else if (variant == 0) h->regen_min_idle = 1;
     else if (variant == 1) h->regen_min_idle = 64;
@@ -616,6 +627,21 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
     return PT_OK;
 }
 
+// Number of consecutive iteration ranges a launch of `tiles` workgroup tiles x `n_iterations`
+// iterations is cut into (render_steal_kernel).
+// Measured on MI355X (demo scene, depth 8, one range -> best): 960x540x64 45 -> 54 G bounces/s
+// with 3..6 ranges, 1080p x 64 60 -> 62 with 2..3, 1080p x 256 62.6 -> 66 with 4, no gain at 4K
+// (32 400 tiles) and none from ranges shorter than 16 iterations.  So: about 16 rounds of
+// workgroups over the chip's ~1536 resident workgroup slots, ranges of at least 16 iterations.
+static uint32_t auto_chunks(uint64_t tiles, uint32_t n_iterations)
+{
+    if (tiles == 0) return 1;
+    uint64_t n = (24576 + tiles / 2) / tiles;
+    const uint32_t longest = n_iterations / 16 < 8 ? n_iterations / 16 : 8;
+    if (n > longest) n = longest;
+    return n < 1 ? 1u : (uint32_t)n;
+}
+
 // Enqueue n iterations on the handle's stream.
 static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
 {
@@ -667,6 +693,25 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
                     (void)hipGetLastError();
             }
             p.steal_scratch = h->d_steal;
+            // chunked launch: more, shorter workgroups (see render_steal_kernel)
+            const uint32_t grid_x = div_up(p.cam.width, 16);
+            uint32_t n_chunks = h->chunks > 0 ? (uint32_t)h->chunks : auto_chunks((uint64_t)grid_x * grid_y, n_iterations);
+            if (n_chunks > n_iterations / 4) n_chunks = n_iterations / 4;   // ranges of at least 4 iterations
+            if (n_chunks > 1) n_chunks = div_up(n_iterations, div_up(n_iterations, n_chunks));   // no empty range
+            if (n_chunks > 1 && (uint64_t)grid_y * n_chunks > 65535u) n_chunks = 1;
+            if (n_chunks > 1 && p.steal_scratch) {
+                const size_t words = 1 + (size_t)grid_x * grid_y;
+                if (words > h->tickets_capacity) {
+                    PT_HIP(h, hipStreamSynchronize(h->stream));
+                    if (h->d_tickets) (void)hipFree(h->d_tickets);
+                    h->d_tickets = nullptr; h->tickets_capacity = 0;
+                    PT_HIP(h, hipMalloc((void **)&h->d_tickets, words * sizeof(uint32_t)));
+                    h->tickets_capacity = words;
+                }
+                PT_HIP(h, hipMemsetAsync(h->d_tickets, 0, words * sizeof(uint32_t), h->stream));
+                p.n_chunks = n_chunks;
+                p.tickets = h->d_tickets;
+            }
         }
         PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
         if (h->integrator == PT_INTEGRATOR_NEE_MIS)

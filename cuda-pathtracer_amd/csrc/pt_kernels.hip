@@ -194,19 +194,51 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
 // At most kStealSlots iterations are taken from one pixel per launch.  Stealing costs nothing
 // until the first lane of a wave runs out of work (one wave-wide test per pass).
 template <bool RING>
-__global__ __launch_bounds__(kBlockThreads) void render_steal_kernel(const RenderParams p)
+__global__ __launch_bounds__(kBlockThreads, 6) void render_steal_kernel(const RenderParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+
+    // ---- tile and iteration range of this workgroup ------------------------------------------------------
+    // Plain launch: the tile is the block index, the workgroup renders all iterations.
+    // Chunked launch (p.n_chunks > 1, grid.y = n_chunks x tile rows): the iterations are cut into
+    // n_chunks consecutive ranges rendered by different workgroups one after the other, each
+    // continuing from the frame-buffer values its predecessor left (what consecutive launches would
+    // do).  More, shorter workgroups leave fewer SIMDs idle while the last ones of a launch finish.
+    // Workgroups take a ticket in the order they START: tickets 0 .. tiles-1 are range 0 of every
+    // tile, and so on, so the workgroup a range waits for has always started already and never
+    // waits for a later ticket itself -- no deadlock, whatever order blocks are dispatched in.
+    uint32_t bx = blockIdx.x, by = blockIdx.y, chunk = 0, tile = 0;
+    uint32_t first_it = p.first_iteration, n_it = p.n_iterations;
+    if (p.n_chunks > 1) {
+        __shared__ uint32_t s_ticket;
+        if (tid == 0) s_ticket = atomicAdd(p.tickets, 1u);
+        __syncthreads();
+        const uint32_t n_tiles = gridDim.x * (gridDim.y / p.n_chunks);
+        chunk = s_ticket / n_tiles;
+        tile = s_ticket - chunk * n_tiles;
+        by = tile / gridDim.x;
+        bx = tile - by * gridDim.x;
+        const uint32_t per = (p.n_iterations + p.n_chunks - 1) / p.n_chunks;   // host: no range is empty
+        first_it = p.first_iteration + chunk * per;
+        n_it = p.n_iterations - chunk * per < per ? p.n_iterations - chunk * per : per;
+        if (chunk > 0) {
+            if (tid == 0) {
+                while (__hip_atomic_load(p.tickets + 1 + tile, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk)
+                    __builtin_amdgcn_s_sleep(16);
+            }
+            __syncthreads();
+        }
+    }
     const SceneView sc = stage_scene<false>(p.scene, lds_raw, tid);
 
     const uint32_t blocks_per_band = p.band_rows >> 4;
-    const uint32_t band_local = blockIdx.y / blocks_per_band;
+    const uint32_t band_local = by / blocks_per_band;
     const uint32_t band = band_local * p.band_world + p.band_rank;
-    const uint32_t yb = p.y0 + band * p.band_rows + (blockIdx.y - band_local * blocks_per_band) * 16u;
-    const uint32_t wave_x0 = p.x0 + blockIdx.x * 16u + (uint32_t)((wave & 1) * 8);
+    const uint32_t yb = p.y0 + band * p.band_rows + (by - band_local * blocks_per_band) * 16u;
+    const uint32_t wave_x0 = p.x0 + bx * 16u + (uint32_t)((wave & 1) * 8);
     const uint32_t wave_y0 = yb + (uint32_t)((wave >> 1) * 8);
     const uint32_t x = wave_x0 + (uint32_t)(lane & 7), y = wave_y0 + (uint32_t)(lane >> 3);
     const bool valid = x < p.x1 && y < p.y1;
@@ -215,14 +247,14 @@ __global__ __launch_bounds__(kBlockThreads) void render_steal_kernel(const Rende
     const V3 cam_pos = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
     const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
     const int mb = p.max_bounces;
-    const uint32_t first = p.first_iteration;
-    const uint32_t it_end = p.first_iteration + p.n_iterations;
+    const uint32_t first = first_it;
+    const uint32_t it_end = first_it + n_it;
 
     // ---- this lane's pixel -------------------------------------------------------------------------
     uint32_t it = first;                     // next own iteration to start
     uint32_t own_end = valid ? it_end : first;   // own iterations are [first, own_end); thieves lower it
     V3 acc = mk(0.f, 0.f, 0.f);
-    if (valid && !p.overwrite && p.buffer) {
+    if (valid && (!p.overwrite || chunk > 0) && p.buffer) {
         const float *px = p.buffer + (size_t)pix * 3;
         acc = mk(px[0], px[1], px[2]);
     }
@@ -367,9 +399,16 @@ __global__ __launch_bounds__(kBlockThreads) void render_steal_kernel(const Rende
             acc = accumulate_pixel(acc, cs, k, p.accum_mode);
         }
     }
-    if (valid && p.buffer && p.n_iterations) {
+    if (valid && p.buffer && n_it) {
         float *px = p.buffer + (size_t)pix * 3;
         px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
+    }
+    if (p.n_chunks > 1) {
+        // hand the tile's frame-buffer values to the workgroup that renders its next range
+        __threadfence();
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(p.tickets + 1 + tile, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     const uint32_t total = wave_sum(nrays);
     if (lane == 0 && p.ray_counter && total) atomicAdd(p.ray_counter, (unsigned long long)total);
@@ -479,8 +518,9 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y
     // Work stealing inside the wave: scenes staged in LDS, plain renders, regeneration on
     if (p.steal_scratch && !tiled && !bvh && !record && p.regen_min_idle <= 1) {
         const size_t lds = render_lds_bytes(p.scene, false, ring);
-        if (ring) hipLaunchKernelGGL((render_steal_kernel<true>), grid, block, lds, stream, p);
-        else      hipLaunchKernelGGL((render_steal_kernel<false>), grid, block, lds, stream, p);
+        const dim3 sgrid(grid_x, grid_y * (p.n_chunks > 1 ? p.n_chunks : 1u));
+        if (ring) hipLaunchKernelGGL((render_steal_kernel<true>), sgrid, block, lds, stream, p);
+        else      hipLaunchKernelGGL((render_steal_kernel<false>), sgrid, block, lds, stream, p);
         return hipGetLastError();
     }
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : render_lds_bytes(p.scene, tiled, ring);

@@ -229,7 +229,9 @@ def test_work_stealing_variant_is_bit_exact(pt, O, torch_cuda):
         mats, sph, lights, (eye, look, up, fov) = pt.build_scene(scene, 1)
         cam = pt.Camera(eye, look, up, w, h, 0, 0, fov)
         imgs, rays = {}, {}
-        for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING, pt.VARIANT_STEALING + 1, pt.VARIANT_AUTO):
+        # + 1: without the camera-ray ring; + 11, + 13: the launch cut into 2 / 4 iteration ranges
+        for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING, pt.VARIANT_STEALING + 1,
+                        pt.VARIANT_STEALING + 11, pt.VARIANT_STEALING + 13, pt.VARIANT_AUTO):
             tr = pt.Pathtracer(cam, depth, 5)
             tr.Init(mats, sph, lights)
             tr.SetKernelVariant(variant)
@@ -249,11 +251,11 @@ def test_work_stealing_variant_is_bit_exact(pt, O, torch_cuda):
             ref, _, _, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, 5, depth, n_iterations=n)
             assert imgs[pt.VARIANT_STEALING] == ref.tobytes(), (scene, w, h)
             assert rays[pt.VARIANT_STEALING] == ref_rays
-    # sum buffer and row bands
+    # sum buffer and row bands; 48 iterations on a small image: the default cuts the launch into 3 ranges
     mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO, 1)
     cam = pt.Camera(eye, look, up, 80, 72, 0, 0, fov)
     out = {}
-    for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING):
+    for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING, pt.VARIANT_STEALING + 12):
         tr = pt.Pathtracer(cam, 8, 3)
         tr.Init(mats, sph, lights)
         tr.SetKernelVariant(variant)
@@ -261,11 +263,12 @@ def test_work_stealing_variant_is_bit_exact(pt, O, torch_cuda):
         tr.SetRowBands(16, 1, 3)
         buf = torch_cuda.zeros(80 * 72 * 3, dtype=torch_cuda.float32, device="cuda")
         tr.RunN(buf, 10)
-        tr.RunN(buf, 6)
+        tr.RunN(buf, 48)
         torch_cuda.cuda.synchronize()
         out[variant] = buf.cpu().numpy().tobytes()
         tr.Release()
     assert out[pt.VARIANT_STEALING] == out[pt.VARIANT_REGENERATION]
+    assert out[pt.VARIANT_STEALING + 12] == out[pt.VARIANT_REGENERATION]
 
 
 def test_tile_split_is_bit_exact(pt, torch_cuda):
