@@ -39,7 +39,76 @@ struct Builder {
     const float4 *sph;
     BvhData *out;
 
-    // Recursive median split on the widest axis of the centroid bounds.
+    static float half_area(const float lo[3], const float hi[3])
+    {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+
+    void sort_axis(size_t lo, size_t hi, int axis)
+    {
+        std::sort(items.begin() + lo, items.begin() + hi, [axis](const Item &x, const Item &y) {
+            return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.index < y.index);
+        });
+    }
+
+    // Where to cut items[lo, hi) (sorted along the returned axis on return): surface-area
+    // heuristic over the three axes, restricted to cuts that
+    //   - leave a multiple of the leaf size on the left, so that leaves come out full (a plain
+    //     median split of 10 000 spheres fills its 4-slot leaves to 65 %: 3856 leaves instead of
+    //     2500, and every leaf visit tests 4 slots whether they are used or not);
+    //   - keep both sides between 3/8 and 5/8 of the range, which bounds the depth (the traversal
+    //     stack lives in LDS, one entry per level) at little cost in tree quality.
+    // Cost of a cut = area(left) * leaves(left) + area(right) * leaves(right).  Ranges above
+    // kSweepMax items are cut at the (rounded) median of the widest axis instead: the sweep sorts
+    // the range three times.
+    size_t choose_split(size_t lo, size_t hi, const float cmin[3], const float cmax[3])
+    {
+        const size_t n = hi - lo, L = kBvhLeafSize;
+        size_t k_mid = ((n / 2 + L / 2) / L) * L;
+        if (k_mid < L) k_mid = L;
+        if (k_mid >= n) k_mid = n - 1;
+        int widest = 0;
+        for (int a = 1; a < 3; ++a)
+            if (cmax[a] - cmin[a] > cmax[widest] - cmin[widest]) widest = a;
+        constexpr size_t kSweepMax = 1u << 15;
+        if (n > kSweepMax) {
+            std::nth_element(items.begin() + lo, items.begin() + lo + k_mid, items.begin() + hi,
+                             [widest](const Item &x, const Item &y) {
+                                 return x.c[widest] < y.c[widest] || (x.c[widest] == y.c[widest] && x.index < y.index);
+                             });
+            return lo + k_mid;
+        }
+        size_t k_lo = ((n * 3 / 8 + L - 1) / L) * L, k_hi = (n - n * 3 / 8) / L * L;
+        if (k_lo < L) k_lo = L;
+        if (k_hi >= n) k_hi = (n - 1) / L * L;
+        if (k_lo > k_hi) { k_lo = k_hi = k_mid; }
+        float best_cost = INFINITY;
+        int best_axis = widest;
+        size_t best_k = k_mid;
+        std::vector<float> right_area(n + 1);
+        for (int axis = 0; axis < 3; ++axis) {
+            sort_axis(lo, hi, axis);
+            float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (size_t i = n; i-- > 0;) {
+                const Item &it = items[lo + i];
+                for (int a = 0; a < 3; ++a) { blo[a] = std::min(blo[a], it.c[a] - it.R); bhi[a] = std::max(bhi[a], it.c[a] + it.R); }
+                right_area[i] = half_area(blo, bhi);
+            }
+            for (int a = 0; a < 3; ++a) { blo[a] = INFINITY; bhi[a] = -INFINITY; }
+            for (size_t i = 0; i < n; ++i) {
+                const Item &it = items[lo + i];
+                for (int a = 0; a < 3; ++a) { blo[a] = std::min(blo[a], it.c[a] - it.R); bhi[a] = std::max(bhi[a], it.c[a] + it.R); }
+                const size_t k = i + 1;   // items on the left
+                if (k < k_lo || k > k_hi || (k % L != 0 && k != k_mid)) continue;
+                const float cost = half_area(blo, bhi) * (float)((k + L - 1) / L) + right_area[k] * (float)((n - k + L - 1) / L);
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_k = k; }
+            }
+        }
+        if (best_axis != 2) sort_axis(lo, hi, best_axis);
+        return lo + best_k;
+    }
+
     Subtree build(size_t lo, size_t hi)
     {
         Subtree me;
@@ -70,14 +139,7 @@ struct Builder {
         }
         const int node = (int)(out->nodes.size() / 4);
         out->nodes.resize(out->nodes.size() + 4);
-        int axis = 0;
-        for (int a = 1; a < 3; ++a)
-            if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
-        const size_t mid = (lo + hi) / 2;
-        std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
-                         [axis](const Item &x, const Item &y) {
-                             return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.index < y.index);
-                         });
+        const size_t mid = choose_split(lo, hi, cmin, cmax);
         const Subtree c0 = build(lo, mid);
         const Subtree c1 = build(mid, hi);
         float r0, r1;

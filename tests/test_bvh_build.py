@@ -33,6 +33,9 @@ def check(pt, sph):
     lo = np.stack([nodes[:, 0:3], nodes[:, 6:9]], 1)              # [node][child][xyz]
     hi = np.stack([np.column_stack([nodes[:, 3], nodes[:, 4], nodes[:, 5]]), nodes[:, 9:12]], 1)
 
+    bounded = np.setdiff1d(np.arange(len(sph)), big)
+    extent = float(np.abs(sph["pos"][bounded]).max() + np.abs(sph["radius"][bounded]).max())
+
     def walk(ref, depth):
         if ref < 0:
             idx = leaf[~ref]
@@ -45,7 +48,7 @@ def check(pt, sph):
             cl, ch, cd = walk(int(refs[ref, k]), depth + 1)
             assert (lo[ref, k] <= cl).all() and (hi[ref, k] >= ch).all(), (ref, k)
             # ... and not by much: slack is 1e-4 + 1e-6 of the cloud's size
-            tol = 0.01 + 1e-5 * max(np.abs(cl).max(), np.abs(ch).max())
+            tol = 0.01 + 1e-5 * extent
             assert (cl - lo[ref, k]).max() < tol and (hi[ref, k] - ch).max() < tol
             mins.append(cl); maxs.append(ch); d = max(d, cd)
         return np.minimum(*mins), np.maximum(*maxs), d + 1
@@ -61,8 +64,10 @@ def test_invariants_on_random_scenes(pt):
     for n in (193, 1000, 10000):
         b = check(pt, scene(pt, rng, n))
         assert b is not None and len(b["big_index"]) == 6
-        assert len(b["leaf_index"]) >= n / 4
-        assert b["depth"] <= np.ceil(np.log2(max(n / 4, 1))) + 1      # median splits: balanced
+        # cuts leave multiples of the leaf size on the left: leaves are full
+        assert len(b["leaf_index"]) == -(-n // 4)
+        # both sides of a cut hold between 3/8 and 5/8 of the range
+        assert b["depth"] <= np.ceil(np.log(max(n / 4, 1)) / np.log(8 / 5)) + 1
 
 
 def test_degenerate_inputs(pt):
