@@ -170,7 +170,7 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->timed = false;
     h->wavefront = false;
     h->auto_variant = true;
-    h->wf_dynamic_fetch = 44;
+    h->wf_dynamic_fetch = 32;
     memset(h->wf_queue, 0, sizeof h->wf_queue);
     h->wf_radiance = nullptr;
     h->wf_counts = nullptr;
@@ -487,13 +487,13 @@ int pt_set_kernel_variant(pt_handle h, int variant)
     h->small_scene_opts = 1;
     h->steal = false;
     h->chunks = 0;
-    h->wf_dynamic_fetch = 44;
+    h->wf_dynamic_fetch = 32;
     if (variant == PT_VARIANT_AUTO) { h->auto_variant = true; h->regen_min_idle = 1; h->steal = true; }
     else if (variant >= PT_VARIANT_WAVEFRONT && variant <= PT_VARIANT_WAVEFRONT + 64) {
         // +1: static assignment of paths to lanes; +2..+64: refill threshold of the dynamic fetch (A/B)
         h->wavefront = true;
         const int k = variant - PT_VARIANT_WAVEFRONT;
-        h->wf_dynamic_fetch = k == 0 ? 44 : (k == 1 ? 0 : k);
+        h->wf_dynamic_fetch = k == 0 ? 32 : (k == 1 ? 0 : k);
     }
     else if (variant >= 300 && variant <= 301) { h->regen_min_idle = 1; h->small_scene_opts = variant - 300; } // experiments
     else if (variant == PT_VARIANT_STEALING) { h->regen_min_idle = 1; h->steal = true; }
