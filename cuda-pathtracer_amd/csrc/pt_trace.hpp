@@ -148,6 +148,7 @@ PT_DEV bool bvh_box_test(float lx, float ly, float lz, float hx, float hy, float
     float tfar;
     bool hit = slab_test(lx, ly, lz, hx, hy, hz, ray, tmax, tnear, tfar);
     if (hit && refine) {
+        PT_LS(22);
         const float e1 = m.at(__builtin_fminf(tfar * 1.00001f, tmax));
         if (e1 < e0) {
             BvhRay narrow;
@@ -241,6 +242,7 @@ PT_DEV bool bvh_begin(const BvhParams &B, V3 o, V3 d, float &tmax, int &best, Bv
 // when the traversal is finished (stack empty).
 PT_DEV bool bvh_node_step(const BvhParams &B, uint2 *stack, V3 o, float tmax, BvhTraversal &tr)
 {
+    PT_LS(23);
     const float4 *N = B.nodes + 4 * (size_t)tr.cur;
     const float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
     float tn0, tn1;
@@ -265,6 +267,7 @@ PT_DEV bool bvh_node_step(const BvhParams &B, uint2 *stack, V3 o, float tmax, Bv
 // One leaf (tr.cur < 0): its four sphere slots, then the next deferred box.
 PT_DEV bool bvh_leaf_step(const BvhParams &B, uint2 *stack, V3 o, V3 d, float &tmax, int &best, BvhTraversal &tr)
 {
+    PT_LS(24);
     const uint32_t leaf = (uint32_t)~tr.cur;
     const float4 *S = B.leaf_sph + 4 * (size_t)leaf;
     const float4 s0 = S[0], s1 = S[1], s2 = S[2], s3 = S[3];

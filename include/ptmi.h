@@ -214,7 +214,8 @@ int pt_accel_stats(pt_handle h, uint64_t out[32]);
  * 1 path start, 2 sphere test, 3 its square-root part, 4 loop pass, 5 bounce shading, 6 emission,
  * 7 throughput update, 8 Russian roulette, 10 BSDF sample, 11/13 its glass-only parts, 12/14 its
  * diffuse-only parts, 15 mirror direction, 16 normalised direction, 17 lanes with a ray in a pass,
- * 18 path end, 19 pixel-iteration end.  Has no counterpart in the reference (measurement only). */
+ * 18 path end, 19 pixel-iteration end, 20 steal attempt, 21 steal, 22 BVH box re-test with the
+ * narrowed widening (two per inner step at most), 23 BVH inner step, 24 BVH leaf step.  Has no counterpart in the reference (measurement only). */
 int pt_lane_stats(pt_handle h, uint64_t out[64]);
 /* HIP-event time of the last pt_run/pt_run_n launch in milliseconds (waits for it). */
 int pt_last_kernel_ms(pt_handle h, float *ms);

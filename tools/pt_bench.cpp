@@ -63,9 +63,9 @@ int main(int argc, char **argv)
             static const char *site[32] = {"ring refill", "path start", "sphere test", "sphere sqrt part", "loop pass",
                 "bounce shading", "emission", "throughput update", "russian roulette", "", "bsdf sample", "glass part 1",
                 "diffuse part 1", "glass part 2", "diffuse part 2", "mirror direction", "normalised direction",
-                "lanes with a ray", "path end", "pixel-iteration end", "steal attempt", "steal"};
+                "lanes with a ray", "path end", "pixel-iteration end", "steal attempt", "steal", "bvh box refinement", "bvh inner step", "bvh leaf step"};
             printf("  lane statistics: site, wave executions, executions per loop pass, mean active lanes / 64\n");
-            for (int i = 0; i < 22; ++i)
+            for (int i = 0; i < 25; ++i)
                 if (ls[2 * i])
                     printf("    %2d %-22s %12llu  %7.3f  %6.3f\n", i, site[i], (unsigned long long)ls[2 * i],
                            (double)ls[2 * i] / (double)ls[8], (double)ls[2 * i + 1] / (64.0 * (double)ls[2 * i]));
