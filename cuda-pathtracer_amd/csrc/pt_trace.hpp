@@ -83,6 +83,47 @@ PT_DEV void scan_lds(const float4 *sph, int base, int count, V3 o, V3 d, float &
     for (; i < count; ++i) sphere_test(sph[i], base + i, o, d, tmax, best);
 }
 
+// Second half of sphere_test (primitive.h:43-44, scene.h:78-80) for a discriminant already computed.
+PT_DEV void sphere_accept(float b, float det, int index, float &tmax, int &best)
+{
+    if (!(det < 0.f)) {
+        const float sq = pt_sqrt(det);
+        float t = b - sq;
+        if (!(t > PT_EPSILON)) t = b + sq;
+        if (t > PT_EPSILON && t < tmax) { tmax = t; best = index; }
+    }
+}
+
+// scan_lds for scenes of thousands of spheres, where a wave's rays meet few of them (on the
+// 10 007-sphere scene 2 % of the spheres have a non-negative discriminant for any lane): the first
+// halves of eight sphere tests run back to back, and ONE test of the eight sign bits decides whether
+// any second half is needed -- an eighth of the compares and branches of the plain loop (groups of
+// 4: +2.5 %, of 8: +6 %, of 16: no more).  The
+// second halves, when needed, run in index order.  (A NaN discriminant with its sign bit set is
+// skipped here and rejected there: no difference in the result.)
+PT_DEV void scan_lds_sparse(const float4 *sph, int base, int count, V3 o, V3 d, float &tmax, int &best)
+{
+    int i = 0;
+    for (; i + 8 <= count; i += 8) {
+        float b[8], det[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 s = sph[i + k];
+            const float opx = s.x - o.x, opy = s.y - o.y, opz = s.z - o.z;
+            b[k] = opx * d.x + opy * d.y + opz * d.z;
+            det[k] = b[k] * b[k] - (opx * opx + opy * opy + opz * opz) + s.w;
+        }
+        uint32_t all_negative = __float_as_uint(det[0]);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) all_negative &= __float_as_uint(det[k]);
+        if (!(all_negative & 0x80000000u)) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sphere_accept(b[k], det[k], base + i + k, tmax, best);
+        }
+    }
+    for (; i < count; ++i) sphere_test(sph[i], base + i, o, d, tmax, best);
+}
+
 // The sphere test with the order-independent acceptance rule of the BVH search: the brute-force
 // scan keeps the lowest index among equal distances because it visits spheres in index order;
 // visiting them in any order, (t, index) must be compared lexicographically to get the same.
@@ -372,7 +413,7 @@ PT_DEV void intersect_scene(const SceneParams &p, const SceneView &sc, unsigned 
             __syncthreads();
             for (uint32_t i = tid; i < count; i += kBlockThreads) lds_sph[i] = p.sph[base + i];
             __syncthreads();
-            if (active) scan_lds(lds_sph, (int)base, (int)count, o, d, tmax, best);
+            if (active) scan_lds_sparse(lds_sph, (int)base, (int)count, o, d, tmax, best);
         }
     } else {
         if (active) scan_lds(sc.sph, 0, (int)p.n_prims, o, d, tmax, best);
