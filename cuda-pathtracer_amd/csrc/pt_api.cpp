@@ -680,8 +680,12 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
     }
     const bool tiled = scene_streams(p.scene);
     if (grid_y > 0) {
-        if (h->steal && !tiled && p.scene.bvh.n_nodes == 0 && h->integrator == PT_INTEGRATOR_PATH && n_iterations >= 4) {
-            const size_t pixels = (size_t)p.cam.width * p.cam.height;
+        // scratch of the work-stealing kernel: 96 bytes per pixel, at most 4 GiB (larger frames render
+        // without stealing)
+        const size_t pixels = (size_t)p.cam.width * p.cam.height;
+        const bool scratch_fits = pixels * kStealSlots * 3 * sizeof(float) <= ((size_t)4 << 30);
+        if (h->steal && scratch_fits && !tiled && p.scene.bvh.n_nodes == 0 && h->integrator == PT_INTEGRATOR_PATH &&
+            n_iterations >= 4) {
             if (pixels > h->steal_capacity) {
                 PT_HIP(h, hipStreamSynchronize(h->stream));
                 if (h->d_steal) (void)hipFree(h->d_steal);

@@ -151,7 +151,8 @@ int pt_reset_counters(pt_handle h);
  *     whole pixel-iterations over from the lane of its wave with the most left.  Applies to scenes
  *     small enough to be staged in LDS (up to 512 spheres, no BVH) with PT_INTEGRATOR_PATH and
  *     launches of at least 4 iterations; allocates 96 bytes of scratch per pixel on first use
- *     (199 MB at 1080p); everything else, or a failed allocation, runs PT_VARIANT_REGENERATION.
+ *     (199 MB at 1080p; frames that would need more than 4 GiB do not steal); everything else, or a
+ *     failed allocation, runs PT_VARIANT_REGENERATION.
  *     Launches of 32 iterations or more over a small frame are also cut into consecutive iteration
  *     ranges rendered by separate workgroups (up to 8, at least 16 iterations each), so that fewer
  *     SIMDs idle while the last workgroups finish; + 1: no camera-ray ring, + 10 + k: k + 1 ranges
