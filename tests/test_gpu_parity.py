@@ -146,6 +146,40 @@ def test_scene_with_more_materials_than_lds_holds(pt, O, torch_cuda):
     tr.Release()
 
 
+def test_empty_and_degenerate_scenes(pt, O, torch_cuda):
+    """Edge cases against the oracle, every kernel variant: no spheres at all (every path is one
+    Intersect call that misses), spheres but no light, a 1x1 image, depth 0, a sphere of radius 0, a
+    sphere with a NaN coordinate and one with an infinite radius."""
+    eye, look, up = [0, 45, 79.5], [0, 35, 0], [0, 1, 0]
+    demo = pt.build_scene(pt.SCENE_DEMO, 1)
+    mats, sph, lights = demo[0], demo[1], demo[2]
+    none_s, none_m, none_l = np.zeros(0, O.SPHERE_DTYPE), np.zeros(0, O.MATERIAL_DTYPE), np.zeros(0, O.LIGHT_DTYPE)
+    dark = sph.copy(); dark["light_id"] = -1
+    weird = sph.copy()
+    weird["radius"][6] = 0.0
+    weird["pos"][7, 1] = np.nan
+    weird = np.concatenate([weird, weird[:1]])
+    weird["radius"][-1] = np.inf
+    cases = [  # materials, spheres, lights, (w, h), depth, iterations
+        (none_m, none_s, none_l, (20, 12), 8, 5), (mats, dark, none_l, (24, 24), 8, 4), (mats, sph, lights, (1, 1), 8, 16),
+        (mats, sph, lights, (33, 18), 0, 6), (mats, weird, lights, (40, 30), 8, 6),
+    ]
+    for m, s, l, (w, h), depth, n in cases:
+        cam = pt.Camera(eye, look, up, w, h, 0, 0, 60.0)
+        ref, _, _, ref_rays = O.oracle_render(cam.pod, m, s, l, 21, depth, n_iterations=n)
+        for variant in (pt.VARIANT_AUTO, pt.VARIANT_REGENERATION, pt.VARIANT_CLASSIC, pt.VARIANT_WAVEFRONT,
+                        pt.VARIANT_STEALING + 11):
+            tr = pt.Pathtracer(cam, depth, 21)
+            tr.Init(m, s, l)
+            tr.SetKernelVariant(variant)
+            tr.ResetCounters()
+            buf = render(torch_cuda, tr, 1, n)
+            assert buf.cpu().numpy().tobytes() == ref.tobytes(), (len(s), w, h, depth, variant)
+            assert tr.RayCount() == ref_rays
+            tr.Release()
+    assert ref_rays > 0
+
+
 def test_debug_trace_sub_rectangle(pt, torch_cuda):
     g = load_golden("demo_64x64_d4_it1")
     tr = make_tracer(pt, g)
