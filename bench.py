@@ -33,7 +33,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# the benchmark configurations of BASELINE.json: configs[1] (the headline), configs[2..4]
+# benchmark workloads: the 1080p demo render is the headline; the others are its 4K, 10k-sphere and mixed-material relatives
 WORKLOADS = {
     "demo1080": dict(scene="SCENE_DEMO", width=1920, height=1080, iterations=64, depth=8,
                      label="demo scene (9 spheres + area light) 1920x1080, 64 iterations of 4 paths per pixel, depth 8"),
