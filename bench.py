@@ -176,9 +176,8 @@ def main():
     tr.SetIntegrator(pt.INTEGRATOR_NEE_MIS if args.integrator == "nee" else pt.INTEGRATOR_PATH)
     bvh = args.accel == "auto" and tr.AccelNodes() > 0
     # what PT_VARIANT_AUTO resolves to (pt_set_kernel_variant in include/ptmi.h)
-    resident = len(sph) <= 512   # staged whole in LDS: the work-stealing megakernel applies
-    eff_variant = args.variant if args.variant >= 0 else (
-        (100 if bvh else (500 if resident else 0)) if args.integrator == "path" else 0)
+    # linear-scan scenes render with the work-stealing megakernel, BVH scenes with the wavefront variant
+    eff_variant = args.variant if args.variant >= 0 else ((100 if bvh else 500) if args.integrator == "path" else 0)
     tr.SetStream(torch.cuda.current_stream().cuda_stream)
     if grouped:
         tr.SetAccumMode(pt.ACCUM_SUM)
@@ -286,7 +285,9 @@ def main():
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS if achieved else None,
                          "traffic": traffic,
-                         "kernel": "render_kernel" if eff_variant < 100 else "wf_step_* (all launches of a step)",
+                         "kernel": ("render_kernel" if eff_variant < 100 else
+                                    "render_steal_kernel" if eff_variant >= 500 else
+                                    "wf_step_* (all launches of a step)"),
                          "launch_ms": launch_ms,
                          "flops_per_bounce": fpr, "bounces_per_launch": rays_per_launch},
         }

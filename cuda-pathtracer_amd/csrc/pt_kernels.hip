@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
 //     (pathtracer.cu:104-109) is kept and the image is bit-identical.
 // At most kStealSlots iterations are taken from one pixel per launch.  Stealing costs nothing
 // until the first lane of a wave runs out of work (one wave-wide test per pass).
-template <bool RING>
+template <bool RING, bool TILED>
 __global__ __launch_bounds__(kBlockThreads, 6) void render_steal_kernel(const RenderParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void render_steal_kernel(const Re
             __syncthreads();
         }
     }
-    const SceneView sc = stage_scene<false>(p.scene, lds_raw, tid);
+    const SceneView sc = stage_scene<TILED>(p.scene, lds_raw, tid);
 
     const uint32_t blocks_per_band = p.band_rows >> 4;
     const uint32_t band_local = by / blocks_per_band;
@@ -352,11 +352,17 @@ __global__ __launch_bounds__(kBlockThreads, 6) void render_steal_kernel(const Re
             b = 0;
             alive = true;
         }
-        if (!__any(alive)) break;
+        // streaming scenes: the scan stages sphere tiles with workgroup barriers, so the four waves
+        // leave the loop together
+        if (TILED) {
+            if (!__syncthreads_or(alive)) break;
+        } else {
+            if (!__any(alive)) break;
+        }
 
         float tmax;
         int best;
-        intersect_scene<false, false>(p.scene, sc, lds_raw, tid, alive, o, d, tmax, best);
+        intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, alive, o, d, tmax, best);
 
         PT_LS(4);
         if (alive) {
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void render_steal_kernel(const Re
             ++nrays;
             bool end = true;
             if (best >= 0)
-                end = shade_bounce(sc, sc.sph[best], best, tmax, tpix, tit, k0, k1, mb, o, d, T, L, b);
+                end = shade_bounce(sc, TILED ? p.scene.sph[best] : sc.sph[best], best, tmax, tpix, tit, k0, k1, mb, o, d, T, L, b);
             if (end) {
                 c = c + L;
                 alive = false;
@@ -515,12 +521,13 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y
     // switch it off).  A branch-free variant of the scan was measured 3.5 % slower and dropped.
     const bool ring = !tiled && p.scene.n_prims <= kMaxRingSpheres && (p.small_scene_opts & 1);
     const bool bvh = p.scene.bvh.n_nodes > 0;   // BVH kernels read the scene from global memory
-    // Work stealing inside the wave: scenes staged in LDS, plain renders, regeneration on
-    if (p.steal_scratch && !tiled && !bvh && !record && p.regen_min_idle <= 1) {
-        const size_t lds = render_lds_bytes(p.scene, false, ring);
+    // Work stealing inside the wave: linear-scan scenes (staged in LDS or streamed), plain renders, regeneration on
+    if (p.steal_scratch && !bvh && !record && p.regen_min_idle <= 1) {
+        const size_t lds = render_lds_bytes(p.scene, tiled, ring);
         const dim3 sgrid(grid_x, grid_y * (p.n_chunks > 1 ? p.n_chunks : 1u));
-        if (ring) hipLaunchKernelGGL((render_steal_kernel<true>), sgrid, block, lds, stream, p);
-        else      hipLaunchKernelGGL((render_steal_kernel<false>), sgrid, block, lds, stream, p);
+        if (tiled)     hipLaunchKernelGGL((render_steal_kernel<false, true>), sgrid, block, lds, stream, p);
+        else if (ring) hipLaunchKernelGGL((render_steal_kernel<true, false>), sgrid, block, lds, stream, p);
+        else           hipLaunchKernelGGL((render_steal_kernel<false, false>), sgrid, block, lds, stream, p);
         return hipGetLastError();
     }
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : render_lds_bytes(p.scene, tiled, ring);

@@ -285,6 +285,23 @@ def test_work_stealing_variant_is_bit_exact(pt, O, torch_cuda):
             ref, _, _, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, 5, depth, n_iterations=n)
             assert imgs[pt.VARIANT_STEALING] == ref.tobytes(), (scene, w, h)
             assert rays[pt.VARIANT_STEALING] == ref_rays
+    # a streaming scene (600 spheres scanned brute force through LDS tiles; the four waves of a
+    # workgroup share the scan's barriers while each steals within itself)
+    from test_oracle_golden import _random_scene
+    mats, sph, lights = _random_scene(np.random.default_rng(3), O, 600)
+    cam = pt.Camera([0, 45, 79.5], [0, 35, 0], [0, 1, 0], 40, 28, 0, 0, 50.0)
+    ref, _, _, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, 8, 6, n_iterations=12)
+    for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING, pt.VARIANT_STEALING + 11):
+        tr = pt.Pathtracer(cam, 6, 8)
+        tr.Init(mats, sph, lights)
+        tr.SetAccel(pt.ACCEL_BRUTE_FORCE)
+        tr.SetKernelVariant(variant)
+        tr.ResetCounters()
+        buf = render(torch_cuda, tr, 1, 12)
+        assert buf.cpu().numpy().tobytes() == ref.tobytes(), variant
+        assert tr.RayCount() == ref_rays
+        tr.Release()
+
     # sum buffer and row bands; 48 iterations on a small image: the default cuts the launch into 3 ranges
     mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO, 1)
     cam = pt.Camera(eye, look, up, 80, 72, 0, 0, fov)
