@@ -16,7 +16,7 @@
 //
 // Scene data: spheres as float4 (cx, cy, cz, r*r) read as wave-uniform LDS broadcasts.  Small
 // scenes are staged once per workgroup; larger ones stream through a 1024-sphere LDS tile.
-#include "pt_trace.hpp"
+#include "pt_nee.hpp"
 
 namespace ptmi {
 
@@ -193,11 +193,11 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
 //     (pathtracer.cu:104-109) is kept and the image is bit-identical.
 // At most kStealSlots iterations are taken from one pixel per launch.  Stealing costs nothing
 // until the first lane of a wave runs out of work (one wave-wide test per pass).
-// Waves per SIMD the register allocation aims at: 6 where LDS (camera-ray ring, sphere tile) allows
-// no more anyway, 7 (72 VGPRs, no spills; 8 would spill) for the plain resident scenes: +3 % on the
+// Waves per SIMD the register allocation aims at: 5 for the NEE integrator (96 VGPRs), 6 where LDS
+// (camera-ray ring, sphere tile) allows no more anyway, 7 (72 VGPRs, no spills; 8 would spill) for the plain resident scenes: +3 % on the
 // 71-sphere scene.
-template <bool RING, bool TILED>
-__global__ __launch_bounds__(kBlockThreads, (RING || TILED) ? 6 : 7) void render_steal_kernel(const RenderParams p)
+template <bool RING, bool TILED, bool NEE>
+__global__ __launch_bounds__(kBlockThreads, NEE ? 5 : ((RING || TILED) ? 6 : 7)) void render_steal_kernel(const RenderParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
 
@@ -273,6 +273,11 @@ __global__ __launch_bounds__(kBlockThreads, (RING || TILED) ? 6 : 7) void render
     int b = 0;
     uint32_t nrays = 0;
     bool stealing = p.steal_scratch != nullptr;   // wave-uniform; cleared once nothing is left to steal
+    // NEE + MIS integrator (see render_nee_kernel): a diffuse vertex parks its direct-light term and
+    // sends the shadow ray through the next pass's Intersect
+    NeeState st;
+    st.shadow = false; st.end_after = false; st.specular_bounce = false; st.bsdf_pdf_prev = 0.f;
+    st.sh_d = mk(0.f, 0.f, 1.f); st.sh_tmax = PT_INF; st.sh_prim = -1; st.pending = mk(0.f, 0.f, 0.f);
 
     // camera-ray ring of the lane's OWN iterations, see render_kernel
     float *ring = reinterpret_cast<float *>(lds_raw + scene_lds_bytes_dev(p.scene));
@@ -354,6 +359,7 @@ __global__ __launch_bounds__(kBlockThreads, (RING || TILED) ? 6 : 7) void render
             L = mk(0.f, 0.f, 0.f);
             b = 0;
             alive = true;
+            if (NEE) { st.shadow = false; st.specular_bounce = false; }
         }
         // streaming scenes: the scan stages sphere tiles with workgroup barriers, so the four waves
         // leave the loop together
@@ -365,15 +371,30 @@ __global__ __launch_bounds__(kBlockThreads, (RING || TILED) ? 6 : 7) void render
 
         float tmax;
         int best;
-        intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, alive, o, d, tmax, best);
+        const bool shadow = NEE && alive && st.shadow;
+        if (NEE) intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, alive, o, shadow ? st.sh_d : d, tmax, best,
+                                              shadow ? st.sh_tmax : PT_INF);
+        else     intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, alive, o, d, tmax, best);
 
         PT_LS(4);
         if (alive) {
             PT_LS(17);
             ++nrays;
             bool end = true;
-            if (best >= 0)
-                end = shade_bounce(sc, TILED ? p.scene.sph[best] : sc.sph[best], best, tmax, tpix, tit, k0, k1, mb, o, d, T, L, b);
+            if (shadow) {
+                const bool visible = st.sh_prim >= 0 ? best == st.sh_prim : best < 0;
+                if (visible) L = L + st.pending;
+                st.shadow = false;
+                end = st.end_after;
+            } else if (best >= 0) {
+                const float4 s = TILED ? p.scene.sph[best] : sc.sph[best];
+                if (NEE) {
+                    end = shade_bounce_nee(p.scene, sc, s, best, tmax, tpix, tit, k0, k1, mb, o, d, T, L, b, st);
+                    if (st.shadow) { st.end_after = end; end = false; }
+                } else {
+                    end = shade_bounce(sc, s, best, tmax, tpix, tit, k0, k1, mb, o, d, T, L, b);
+                }
+            }
             if (end) {
                 c = c + L;
                 alive = false;
@@ -516,6 +537,25 @@ static size_t render_lds_bytes(const SceneParams &s, bool tiled, bool ring)
     return scene_lds_bytes(s, tiled) + (ring ? (size_t)8 * 3 * kBlockThreads * sizeof(float) : 0);
 }
 
+// The work-stealing megakernel (linear-scan scenes, p.steal_scratch set); nee: the NEE + MIS integrator.
+hipError_t launch_render_steal(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled, bool nee,
+                               hipStream_t stream)
+{
+    // no camera-ray ring under NEE: its state needs 96 VGPRs (5 waves per SIMD), the ring's index
+    // arithmetic 12 more (4 waves), which costs more than the ring saves (measured: 85.6 vs 82.4 ms)
+    const bool ring = !nee && !tiled && p.scene.n_prims <= kMaxRingSpheres && (p.small_scene_opts & 1);
+    const size_t lds = render_lds_bytes(p.scene, tiled, ring);
+    const dim3 grid(grid_x, grid_y * (p.n_chunks > 1 ? p.n_chunks : 1u)), block(kBlockThreads);
+#define PT_LAUNCH_STEAL(G, T, N) hipLaunchKernelGGL((render_steal_kernel<G, T, N>), grid, block, lds, stream, p)
+    if (nee) {
+        if (tiled) PT_LAUNCH_STEAL(false, true, true); else PT_LAUNCH_STEAL(false, false, true);
+    } else {
+        if (tiled) PT_LAUNCH_STEAL(false, true, false); else if (ring) PT_LAUNCH_STEAL(true, false, false); else PT_LAUNCH_STEAL(false, false, false);
+    }
+#undef PT_LAUNCH_STEAL
+    return hipGetLastError();
+}
+
 hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled,
                          bool record, hipStream_t stream)
 {
@@ -525,14 +565,7 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y
     const bool ring = !tiled && p.scene.n_prims <= kMaxRingSpheres && (p.small_scene_opts & 1);
     const bool bvh = p.scene.bvh.n_nodes > 0;   // BVH kernels read the scene from global memory
     // Work stealing inside the wave: linear-scan scenes (staged in LDS or streamed), plain renders, regeneration on
-    if (p.steal_scratch && !bvh && !record && p.regen_min_idle <= 1) {
-        const size_t lds = render_lds_bytes(p.scene, tiled, ring);
-        const dim3 sgrid(grid_x, grid_y * (p.n_chunks > 1 ? p.n_chunks : 1u));
-        if (tiled)     hipLaunchKernelGGL((render_steal_kernel<false, true>), sgrid, block, lds, stream, p);
-        else if (ring) hipLaunchKernelGGL((render_steal_kernel<true, false>), sgrid, block, lds, stream, p);
-        else           hipLaunchKernelGGL((render_steal_kernel<false, false>), sgrid, block, lds, stream, p);
-        return hipGetLastError();
-    }
+    if (p.steal_scratch && !bvh && !record && p.regen_min_idle <= 1) return launch_render_steal(p, grid_x, grid_y, tiled, false, stream);
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : render_lds_bytes(p.scene, tiled, ring);
 #define PT_LAUNCH(T, R, G, B) hipLaunchKernelGGL((render_kernel<T, R, G, B>), grid, block, lds, stream, p)
     if (bvh) {

@@ -98,6 +98,9 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y
 
 hipError_t read_lane_stats(unsigned long long out[64]);
 
+hipError_t launch_render_steal(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled, bool nee,
+                               hipStream_t stream);
+
 // The opt-in NEE + MIS integrator (pt_nee.hip); same launch geometry.
 hipError_t launch_render_nee(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled, bool record,
                              hipStream_t stream);
