@@ -684,7 +684,7 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
         // without stealing)
         const size_t pixels = (size_t)p.cam.width * p.cam.height;
         const bool scratch_fits = pixels * kStealSlots * 3 * sizeof(float) <= ((size_t)4 << 30);
-        if (h->steal && scratch_fits && p.scene.bvh.n_nodes == 0 && n_iterations >= 4) {
+        if (h->steal && scratch_fits && n_iterations >= 4) {
             if (pixels > h->steal_capacity) {
                 PT_HIP(h, hipStreamSynchronize(h->stream));
                 if (h->d_steal) (void)hipFree(h->d_steal);

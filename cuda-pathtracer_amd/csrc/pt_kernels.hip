@@ -196,8 +196,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
 // Waves per SIMD the register allocation aims at: 5 for the NEE integrator (96 VGPRs), 6 where LDS
 // (camera-ray ring, sphere tile) allows no more anyway, 7 (72 VGPRs, no spills; 8 would spill) for the plain resident scenes: +3 % on the
 // 71-sphere scene.
-template <bool RING, bool TILED, bool NEE>
-__global__ __launch_bounds__(kBlockThreads, NEE ? 5 : ((RING || TILED) ? 6 : 7)) void render_steal_kernel(const RenderParams p)
+template <bool RING, bool TILED, bool NEE, bool BVH>
+__global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED) ? 6 : 7))) void render_steal_kernel(const RenderParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
 
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kBlockThreads, NEE ? 5 : ((RING || TILED) ? 6 : 7))
         }
         // streaming scenes: the scan stages sphere tiles with workgroup barriers, so the four waves
         // leave the loop together
-        if (TILED) {
+        if (TILED && !BVH) {
             if (!__syncthreads_or(alive)) break;
         } else {
             if (!__any(alive)) break;
@@ -372,9 +372,9 @@ __global__ __launch_bounds__(kBlockThreads, NEE ? 5 : ((RING || TILED) ? 6 : 7))
         float tmax;
         int best;
         const bool shadow = NEE && alive && st.shadow;
-        if (NEE) intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, alive, o, shadow ? st.sh_d : d, tmax, best,
-                                              shadow ? st.sh_tmax : PT_INF);
-        else     intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, alive, o, d, tmax, best);
+        if (NEE) intersect_scene<TILED, BVH>(p.scene, sc, lds_raw, tid, alive, o, shadow ? st.sh_d : d, tmax, best,
+                                            shadow ? st.sh_tmax : PT_INF);
+        else     intersect_scene<TILED, BVH>(p.scene, sc, lds_raw, tid, alive, o, d, tmax, best);
 
         PT_LS(4);
         if (alive) {
@@ -541,16 +541,21 @@ static size_t render_lds_bytes(const SceneParams &s, bool tiled, bool ring)
 hipError_t launch_render_steal(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled, bool nee,
                                hipStream_t stream)
 {
+    // BVH scenes keep the scene in device memory (TILED staging without the sphere tile) and the
+    // per-lane traversal stacks in LDS.
+    const bool bvh = p.scene.bvh.n_nodes > 0;
     // no camera-ray ring under NEE: its state needs 96 VGPRs (5 waves per SIMD), the ring's index
     // arithmetic 12 more (4 waves), which costs more than the ring saves (measured: 85.6 vs 82.4 ms)
-    const bool ring = !nee && !tiled && p.scene.n_prims <= kMaxRingSpheres && (p.small_scene_opts & 1);
-    const size_t lds = render_lds_bytes(p.scene, tiled, ring);
+    const bool ring = !nee && !bvh && !tiled && p.scene.n_prims <= kMaxRingSpheres && (p.small_scene_opts & 1);
+    const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : render_lds_bytes(p.scene, tiled, ring);
     const dim3 grid(grid_x, grid_y * (p.n_chunks > 1 ? p.n_chunks : 1u)), block(kBlockThreads);
-#define PT_LAUNCH_STEAL(G, T, N) hipLaunchKernelGGL((render_steal_kernel<G, T, N>), grid, block, lds, stream, p)
-    if (nee) {
-        if (tiled) PT_LAUNCH_STEAL(false, true, true); else PT_LAUNCH_STEAL(false, false, true);
+#define PT_LAUNCH_STEAL(G, T, N, B) hipLaunchKernelGGL((render_steal_kernel<G, T, N, B>), grid, block, lds, stream, p)
+    if (bvh) {
+        if (nee) PT_LAUNCH_STEAL(false, true, true, true); else PT_LAUNCH_STEAL(false, true, false, true);
+    } else if (nee) {
+        if (tiled) PT_LAUNCH_STEAL(false, true, true, false); else PT_LAUNCH_STEAL(false, false, true, false);
     } else {
-        if (tiled) PT_LAUNCH_STEAL(false, true, false); else if (ring) PT_LAUNCH_STEAL(true, false, false); else PT_LAUNCH_STEAL(false, false, false);
+        if (tiled) PT_LAUNCH_STEAL(false, true, false, false); else if (ring) PT_LAUNCH_STEAL(true, false, false, false); else PT_LAUNCH_STEAL(false, false, false, false);
     }
 #undef PT_LAUNCH_STEAL
     return hipGetLastError();
@@ -565,7 +570,7 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y
     const bool ring = !tiled && p.scene.n_prims <= kMaxRingSpheres && (p.small_scene_opts & 1);
     const bool bvh = p.scene.bvh.n_nodes > 0;   // BVH kernels read the scene from global memory
     // Work stealing inside the wave: linear-scan scenes (staged in LDS or streamed), plain renders, regeneration on
-    if (p.steal_scratch && !bvh && !record && p.regen_min_idle <= 1) return launch_render_steal(p, grid_x, grid_y, tiled, false, stream);
+    if (p.steal_scratch && !record && p.regen_min_idle <= 1) return launch_render_steal(p, grid_x, grid_y, tiled, false, stream);
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : render_lds_bytes(p.scene, tiled, ring);
 #define PT_LAUNCH(T, R, G, B) hipLaunchKernelGGL((render_kernel<T, R, G, B>), grid, block, lds, stream, p)
     if (bvh) {

@@ -148,9 +148,8 @@ int pt_reset_counters(pt_handle h);
  *     (when no row bands are set and the integrator is PT_INTEGRATOR_PATH), else
  *     PT_VARIANT_STEALING
  *   PT_VARIANT_STEALING: PT_VARIANT_REGENERATION, and a lane that has finished its pixel takes
- *     whole pixel-iterations over from the lane of its wave with the most left.  Applies to scenes
- *     rendered by the linear scan (no BVH: up to 192 spheres, or PT_ACCEL_BRUTE_FORCE), either
- *     integrator, and launches of at least 4 iterations; allocates 96 bytes of scratch per pixel on first use
+ *     whole pixel-iterations over from the lane of its wave with the most left.  Applies to every
+ *     megakernel launch of at least 4 iterations (linear scan or BVH, either integrator); allocates 96 bytes of scratch per pixel on first use
  *     (199 MB at 1080p; frames that would need more than 4 GiB do not steal); everything else, or a
  *     failed allocation, runs PT_VARIANT_REGENERATION.
  *     Launches of 32 iterations or more over a small frame are also cut into consecutive iteration
