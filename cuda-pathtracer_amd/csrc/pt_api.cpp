@@ -475,6 +475,7 @@ int pt_lane_stats(pt_handle h, uint64_t out[64])
     PT_HIP(h, hipStreamSynchronize(h->stream));
     unsigned long long v[64];
     PT_HIP(h, read_lane_stats(v));
+    PT_HIP(h, add_lane_stats_wavefront(v));
     for (int i = 0; i < 64; ++i) out[i] = (uint64_t)v[i];
     return PT_OK;
 }

@@ -97,6 +97,7 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y
                          bool record, hipStream_t stream);
 
 hipError_t read_lane_stats(unsigned long long out[64]);
+hipError_t add_lane_stats_wavefront(unsigned long long out[64]);
 
 hipError_t launch_render_steal(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled, bool nee,
                                hipStream_t stream);

@@ -229,6 +229,8 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_bvh_kernel(const Wavefr
 
         // ---- lanes whose traversal is finished: shade, store, free the lane ---------------------
         const bool fin = has && !trav;
+        PT_LS(4);
+        if (fin) PT_LS(17);
         bvh_finish_over_budget(p.scene.sph, p.scene.n_prims, fin && over, o, d, tmax, best);
         bool cont = false;
         if (fin) {
@@ -291,6 +293,22 @@ __global__ __launch_bounds__(kBlockThreads) void wf_resolve_kernel(const Wavefro
 }
 
 } // namespace
+
+// Divergence counters of the kernels in this file (measurement builds only), added to out[64] and cleared.
+hipError_t add_lane_stats_wavefront(unsigned long long out[64])
+{
+#ifdef PT_LANE_STATS
+    unsigned long long v[64];
+    hipError_t e = hipMemcpyFromSymbol(v, HIP_SYMBOL(g_lane_stats), sizeof v);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < 64; ++i) out[i] += v[i];
+    static const unsigned long long zeros[64] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stats), zeros, sizeof zeros);
+#else
+    (void)out;
+    return hipSuccess;
+#endif
+}
 
 hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream_t stream)
 {
