@@ -320,8 +320,21 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
     const bool bvh = p.scene.bvh.n_nodes > 0;   // BVH kernels read the scene from global memory
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : scene_lds_bytes(p.scene, tiled);
     if (bvh && p.dynamic_fetch) {
-        // one resident set of persistent workgroups (LDS: six per CU)
-        const dim3 pgrid(kWfSubQueues, chunks < 24u ? chunks : 24u);
+        // One resident set of persistent workgroups: per CU as many as the traversal stacks in LDS
+        // (2 KiB per tree level) and the kernel's registers (6 waves per SIMD) allow.  More would
+        // run as a second round behind the first and wait for it.
+        static int n_cus = 0;
+        if (n_cus == 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0)
+                n_cus = 256;
+        }
+        uint32_t per_cu = (uint32_t)((160u * 1024u) / (lds ? lds : 1));
+        if (per_cu > 6u) per_cu = 6u;
+        if (per_cu < 1u) per_cu = 1u;
+        uint32_t rows = (per_cu * (uint32_t)n_cus + kWfSubQueues - 1) / kWfSubQueues;
+        const dim3 pgrid(kWfSubQueues, chunks < rows ? chunks : rows);
         hipLaunchKernelGGL((wf_step_bvh_kernel<kBvhNodeStepsPerLeafStep>), pgrid, block, lds, stream, p);
     } else if (bvh) hipLaunchKernelGGL((wf_step_kernel<true, true>), grid, block, lds, stream, p);
     else if (tiled) hipLaunchKernelGGL((wf_step_kernel<true, false>), grid, block, lds, stream, p);
