@@ -703,15 +703,18 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
             if (n_chunks > n_iterations / 4) n_chunks = n_iterations / 4;   // ranges of at least 4 iterations
             if (n_chunks > 1) n_chunks = div_up(n_iterations, div_up(n_iterations, n_chunks));   // no empty range
             if (n_chunks > 1 && (uint64_t)grid_y * n_chunks > 65535u) n_chunks = 1;
-            if (n_chunks > 1 && p.steal_scratch) {
-                const size_t words = 1 + (size_t)grid_x * grid_y;
-                if (words > h->tickets_capacity) {
-                    PT_HIP(h, hipStreamSynchronize(h->stream));
-                    if (h->d_tickets) (void)hipFree(h->d_tickets);
-                    h->d_tickets = nullptr; h->tickets_capacity = 0;
-                    PT_HIP(h, hipMalloc((void **)&h->d_tickets, words * sizeof(uint32_t)));
+            const size_t words = 1 + (size_t)grid_x * grid_y;
+            if (n_chunks > 1 && p.steal_scratch && words > h->tickets_capacity) {
+                PT_HIP(h, hipStreamSynchronize(h->stream));
+                if (h->d_tickets) (void)hipFree(h->d_tickets);
+                h->d_tickets = nullptr; h->tickets_capacity = 0;
+                // without the tickets the launch is simply not cut into ranges
+                if (hipMalloc((void **)&h->d_tickets, words * sizeof(uint32_t)) == hipSuccess)
                     h->tickets_capacity = words;
-                }
+                else
+                    (void)hipGetLastError();
+            }
+            if (n_chunks > 1 && p.steal_scratch && words <= h->tickets_capacity) {
                 PT_HIP(h, hipMemsetAsync(h->d_tickets, 0, words * sizeof(uint32_t), h->stream));
                 p.n_chunks = n_chunks;
                 p.tickets = h->d_tickets;
