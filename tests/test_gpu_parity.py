@@ -322,6 +322,19 @@ def test_work_stealing_variant_is_bit_exact(pt, O, torch_cuda):
     assert out[pt.VARIANT_STEALING + 12] == out[pt.VARIANT_REGENERATION]
 
 
+def test_work_stealing_on_random_cases(pt, torch_cuda):
+    """60 cases of tools/fuzz_steal.py: random frame sizes, iteration counts, depths, scenes, both
+    integrators, sum buffers, row bands, BVH and brute force -- the work-stealing kernel (with and
+    without iteration ranges) against the plain megakernel, bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_steal
+    for seed in range(7000, 7060):
+        ok, what = fuzz_steal.one_case(seed)
+        assert ok, (seed, what)
+
+
 def test_tile_split_is_bit_exact(pt, torch_cuda):
     """Row bands rendered by different instances into zero-filled buffers sum to the 1-instance image."""
     g = load_golden("demo_64x48_d8_it1-4")
