@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
 // Waves per SIMD the register allocation aims at: 5 for the NEE integrator (96 VGPRs), 6 where LDS
 // (camera-ray ring, sphere tile) allows no more anyway, 7 (72 VGPRs, no spills; 8 would spill) for the plain resident scenes: +3 % on the
 // 71-sphere scene.
-template <bool RING, bool TILED, bool NEE, bool BVH>
+template <bool RING, bool TILED, bool NEE, bool BVH, bool UNIT1>
 __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED) ? 6 : 7))) void render_steal_kernel(const RenderParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -251,23 +251,31 @@ __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED
     const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
     const int mb = p.max_bounces;
     const uint32_t first = first_it;
-    const uint32_t it_end = first_it + n_it;
-
     // ---- this lane's pixel -------------------------------------------------------------------------
-    uint32_t it = first;                     // next own iteration to start
-    uint32_t own_end = valid ? it_end : first;   // own iterations are [first, own_end); thieves lower it
+    // The paths of a pixel are numbered g = (iteration - first) * 4 + sub-sample, n_paths = 4 * n_it in
+    // all, and traced in that order.  Work changes hands in UNITS of `unit` consecutive paths: 4 (a
+    // whole pixel-iteration, the thief hands back the 4-path sum c) for long launches, 1 (a single
+    // path, the thief hands back its radiance L) for launches of a few iterations, where a lane
+    // has too few whole iterations to give away.  A lane's own paths are [0, own_end); thieves
+    // take units off its end.
+    const uint32_t n_paths = n_it * 4u;
+    constexpr uint32_t unit = UNIT1 ? 1u : 4u;
+    uint32_t next_own = 0;                    // next own path to start
+    uint32_t own_end = valid ? n_paths : 0u;
     V3 acc = mk(0.f, 0.f, 0.f);
     if (valid && (!p.overwrite || chunk > 0) && p.buffer) {
         const float *px = p.buffer + (size_t)pix * 3;
         acc = mk(px[0], px[1], px[2]);
     }
-    // ---- the pixel-iteration in hand (own or stolen) and its current path --------------------------------
+    // ---- the path in hand (own or stolen) ----------------------------------------------------------
     bool has_task = false, alive = false;
-    uint32_t tpix = pix, tit = first;
-    // -1: the lane's own pixel; else the lane (of this wave) the iteration was taken from, + 64 when
-    // its camera rays sit in that lane's ring
+    uint32_t tpix = pix, tg = 0, tit = first;   // pixel, path number and iteration of the path in hand
+    // -1: the lane's own pixel; else the lane (of this wave) the unit was taken from, + 64 when its
+    // camera rays sit in that lane's ring
     int t_from = -1;
-    int sub = 0;
+    // Running 4-path sum of the OWN pixel's current iteration (pathtracer.cu:95-101); a thief of whole
+    // iterations has none of its own left and builds the stolen iteration's sum here, a thief of
+    // single paths leaves it alone (it may hold the first paths of the lane's last iteration).
     V3 c = mk(0.f, 0.f, 0.f);
     V3 o = cam_pos, d = mk(0.f, 0.f, 1.f), T = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
     int b = 0;
@@ -284,16 +292,18 @@ __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED
     uint32_t gen = 0;    // own pixel-iterations generated into the ring so far
     uint32_t cons = 0;   // own paths started so far
 
-    if (it < own_end) { has_task = true; ++it; }   // the first own iteration (tpix, tit, t_from are set for it)
+    if (next_own < own_end) { has_task = true; ++next_own; }   // the first own path (tpix, tg, tit, t_from are set for it)
 
     for (;;) {
-        // ---- a lane that has finished its own iterations takes the last unstarted one of the lane
-        //      with the most left ----------------------------------------------------------------------------
+        // ---- a lane that has finished its own paths takes the last unstarted unit of the lane with
+        //      the most left ----------------------------------------------------------------------------------
         if (stealing && __any(!has_task)) {
             PT_LS(20);
             for (;;) {
-                // iterations this lane could give away: the ones it has not started
-                const uint32_t spare = (own_end > it && it_end - own_end < kStealSlots) ? own_end - it : 0u;
+                // units this lane could give away: whole ones it has not started
+                const uint32_t first_free = (next_own + unit - 1u) & ~(unit - 1u);
+                const uint32_t spare = (own_end > first_free && (n_paths - own_end) / unit < kStealSlots)
+                                           ? (own_end - first_free) / unit : 0u;
                 uint32_t key = (spare << 6) | (uint32_t)lane;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {
@@ -306,28 +316,27 @@ __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED
                 if (!idle) break;
                 const int thief = __ffsll(idle) - 1;
                 const int victim = (int)(key & 63u);
-                const uint32_t v_it = (uint32_t)__builtin_amdgcn_readlane((int)own_end, victim) - 1u;
+                const uint32_t v_g = (uint32_t)__builtin_amdgcn_readlane((int)own_end, victim) - unit;
                 const uint32_t v_pix = (uint32_t)__builtin_amdgcn_readlane((int)pix, victim);
-                // the victim's ring already holds the camera rays of its next iterations; it will not
-                // write to that slot again (it generates no iteration at or beyond own_end)
+                // the victim's ring may hold the camera rays of the unit already; it will not write to
+                // those slots again (it generates no iteration that starts at or beyond own_end)
                 const uint32_t v_gen = (uint32_t)__builtin_amdgcn_readlane((int)gen, victim);
-                if (lane == victim) own_end = v_it;
+                if (lane == victim) own_end = v_g;
                 if (lane == thief) {
                     PT_LS(21);
                     has_task = true;
-                    tpix = v_pix; tit = v_it;
-                    t_from = victim + ((RING && v_it < first + v_gen) ? 64 : 0);
-                    sub = 0;
-                    c = mk(0.f, 0.f, 0.f);
+                    tpix = v_pix; tg = v_g; tit = first + (v_g >> 2);
+                    t_from = victim + ((RING && (v_g >> 2) < v_gen) ? 64 : 0);
+                    if (unit == 4u) c = mk(0.f, 0.f, 0.f);
                 }
             }
         }
 
-        // ---- next path of the pixel-iteration ------------------------------------------------------------------
+        // ---- start the path in hand --------------------------------------------------------------------------
         const bool want = has_task && !alive;
         if (RING) {
             if (__any(want && t_from < 0 && cons == gen * 4u)) {
-                if (first + gen < own_end && gen * 4u - cons <= 4u) {
+                if (gen * 4u < own_end && gen * 4u - cons <= 4u) {
                     V3 dirs[4];
                     camera_rays4(p.cam, x, y, pix, first + gen, k0, k1, dirs);
                     const uint32_t base = (gen & 1u) * 4u;
@@ -347,13 +356,12 @@ __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED
                 d = mk(slot[0], slot[kBlockThreads], slot[2 * kBlockThreads]);
                 ++cons;
             } else if (RING && t_from >= 64) {
-                const float *slot = ring + ((((tit - first) & 1u) * 4u + (uint32_t)sub) * 3u) * kBlockThreads +
-                                    (tid - lane + (t_from - 64));
+                const float *slot = ring + ((tg & 7u) * 3u) * kBlockThreads + (tid - lane + (t_from - 64));
                 d = mk(slot[0], slot[kBlockThreads], slot[2 * kBlockThreads]);
             } else {
                 const int from = t_from < 0 ? lane : t_from;
-                d = camera_ray(p.cam, wave_x0 + (uint32_t)(from & 7), wave_y0 + (uint32_t)(from >> 3), tpix, tit, sub,
-                               k0, k1);
+                d = camera_ray(p.cam, wave_x0 + (uint32_t)(from & 7), wave_y0 + (uint32_t)(from >> 3), tpix, tit,
+                               (int)(tg & 3u), k0, k1);
             }
             T = mk(1.f, 1.f, 1.f);
             L = mk(0.f, 0.f, 0.f);
@@ -396,37 +404,55 @@ __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED
                 }
             }
             if (end) {
-                c = c + L;
                 alive = false;
-                if (++sub == 4) {
-                    if (t_from >= 0) {
-                        float *slot = p.steal_scratch + ((size_t)tpix * kStealSlots + (it_end - 1u - tit)) * 3;
-                        slot[0] = c.x; slot[1] = c.y; slot[2] = c.z;
-                    } else {
+                const bool last_of_iteration = (tg & 3u) == 3u;
+                if (t_from < 0) {
+                    // own path: the running sum, and the running mean once the iteration is complete
+                    c = c + L;
+                    if (last_of_iteration) {
                         acc = accumulate_pixel(acc, c, tit, p.accum_mode);
+                        c = mk(0.f, 0.f, 0.f);
                     }
-                    // next own iteration, if any is left (a thief has none: it only steals once it == own_end)
-                    has_task = it < own_end;
+                    has_task = next_own < own_end;
+                    tg = next_own;
+                    next_own += has_task ? 1u : 0u;
+                    tit = first + (tg >> 2);
+                } else if (unit == 4u && !last_of_iteration) {
+                    // stolen iteration: on to its next path
+                    c = c + L;
+                    ++tg;
+                } else {
+                    // stolen unit complete: leave the 4-path sum, or the path's radiance, for the owner
+                    const V3 v = unit == 4u ? c + L : L;
+                    float *slot = p.steal_scratch + ((size_t)tpix * kStealSlots + ((n_paths - tg - 1u) / unit)) * 3;
+                    slot[0] = v.x; slot[1] = v.y; slot[2] = v.z;
+                    if (unit == 4u) c = mk(0.f, 0.f, 0.f);
+                    has_task = false;   // a thief has no paths of its own left
                     t_from = -1;
-                    tpix = pix; tit = it;
-                    it += has_task ? 1u : 0u;
-                    sub = 0;
-                    c = mk(0.f, 0.f, 0.f);
+                    tpix = pix;
                 }
             }
         }
     }
 
-    // ---- the iterations other lanes of this wave rendered for this pixel, in order --------------------------------
-    if (own_end < it_end && valid) {
+    // ---- the units other lanes of this wave rendered for this pixel, in order -----------------------------------
+    if (own_end < n_paths && valid) {
         __threadfence_block();   // their results were stored by this same wave
-        for (uint32_t k = own_end; k < it_end; ++k) {
-            const float *slot = p.steal_scratch + ((size_t)pix * kStealSlots + (it_end - 1u - k)) * 3;
+        for (uint32_t g = own_end; g < n_paths; g += unit) {
+            const float *slot = p.steal_scratch + ((size_t)pix * kStealSlots + ((n_paths - g - 1u) / unit)) * 3;
             // read past the vector cache: the line may have been cached before a thief wrote to it
-            const V3 cs = mk(__hip_atomic_load(slot + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                             __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                             __hip_atomic_load(slot + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            acc = accumulate_pixel(acc, cs, k, p.accum_mode);
+            const V3 v = mk(__hip_atomic_load(slot + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                            __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                            __hip_atomic_load(slot + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (unit == 4u) {
+                acc = accumulate_pixel(acc, v, first + (g >> 2), p.accum_mode);
+            } else {
+                c = c + v;
+                if ((g & 3u) == 3u) {
+                    acc = accumulate_pixel(acc, c, first + (g >> 2), p.accum_mode);
+                    c = mk(0.f, 0.f, 0.f);
+                }
+            }
         }
     }
     if (valid && p.buffer && n_it) {
@@ -549,7 +575,11 @@ hipError_t launch_render_steal(const RenderParams &p, uint32_t grid_x, uint32_t 
     const bool ring = !nee && !bvh && !tiled && p.scene.n_prims <= kMaxRingSpheres && (p.small_scene_opts & 1);
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : render_lds_bytes(p.scene, tiled, ring);
     const dim3 grid(grid_x, grid_y * (p.n_chunks > 1 ? p.n_chunks : 1u)), block(kBlockThreads);
-#define PT_LAUNCH_STEAL(G, T, N, B) hipLaunchKernelGGL((render_steal_kernel<G, T, N, B>), grid, block, lds, stream, p)
+#define PT_LAUNCH_STEAL(G, T, N, B)                                                                              \
+    do {                                                                                                          \
+        if (p.steal_unit == 1) hipLaunchKernelGGL((render_steal_kernel<G, T, N, B, true>), grid, block, lds, stream, p); \
+        else hipLaunchKernelGGL((render_steal_kernel<G, T, N, B, false>), grid, block, lds, stream, p);           \
+    } while (0)
     if (bvh) {
         if (nee) PT_LAUNCH_STEAL(false, true, true, true); else PT_LAUNCH_STEAL(false, true, false, true);
     } else if (nee) {

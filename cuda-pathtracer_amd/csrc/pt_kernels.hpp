@@ -76,6 +76,7 @@ struct RenderParams {
     // work stealing inside the wave (render_steal_kernel): [width*height][kStealSlots][3] floats of
     // scratch for the pixel-iterations rendered by another lane than the pixel's; NULL: no stealing
     float *steal_scratch;
+    int steal_unit;           // paths that change hands at a time: 4 (a pixel-iteration) or 1
     // chunked launch of render_steal_kernel: n_chunks consecutive iteration ranges, one workgroup per
     // tile and range; tickets[0] = start-order counter, tickets[1 + tile] = ranges of the tile done
     uint32_t n_chunks;

@@ -148,14 +148,15 @@ int pt_reset_counters(pt_handle h);
  *     (when no row bands are set and the integrator is PT_INTEGRATOR_PATH), else
  *     PT_VARIANT_STEALING
  *   PT_VARIANT_STEALING: PT_VARIANT_REGENERATION, and a lane that has finished its pixel takes
- *     whole pixel-iterations over from the lane of its wave with the most left.  Applies to every
- *     megakernel launch of at least 4 iterations (linear scan or BVH, either integrator); allocates 96 bytes of scratch per pixel on first use
+ *     work over from the lane of its wave with the most left: whole pixel-iterations, or single
+ *     paths in launches of up to 5 iterations (pt_run's one iteration per call: +23 %).  Applies to
+ *     every megakernel launch (linear scan or BVH, either integrator); allocates 96 bytes of scratch per pixel on first use
  *     (199 MB at 1080p; frames that would need more than 4 GiB do not steal); everything else, or a
  *     failed allocation, runs PT_VARIANT_REGENERATION.
  *     Launches of 32 iterations or more over a small frame are also cut into consecutive iteration
  *     ranges rendered by separate workgroups (up to 8, at least 16 iterations each), so that fewer
- *     SIMDs idle while the last workgroups finish; + 1: no camera-ray ring, + 10 + k: k + 1 ranges
- *     (experiments)
+ *     SIMDs idle while the last workgroups finish; + 1: no camera-ray ring, + 2 / + 3: single paths /
+ *     whole pixel-iterations change hands, + 10 + k: k + 1 ranges (experiments)
  *   PT_VARIANT_REGENERATION: megakernel, persistent lanes with path regeneration
  *   PT_VARIANT_CLASSIC: megakernel, a wave starts new paths only when all its lanes are idle
  *   2..64: megakernel, regeneration once that many lanes of a wave are idle (experiments)

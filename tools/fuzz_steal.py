@@ -49,14 +49,16 @@ def one_case(seed):
             accel = pt.ACCEL_BRUTE_FORCE
     w, h = int(rng.integers(1, 140)), int(rng.integers(1, 100))
     depth = int(rng.choice([0, 2, 8, 16]))
-    n = int(rng.choice([4, 5, 16, 33, 70]))
+    n = int(rng.choice([1, 2, 3, 4, 5, 16, 33, 70]))
     first = int(rng.choice([1, 1, 3]))
     mode = int(rng.choice([pt.ACCUM_RUNNING_MEAN, pt.ACCUM_SUM]))
     bands = (16, int(rng.integers(0, 3)), 3) if rng.random() < 0.3 else None
     integrator = pt.INTEGRATOR_NEE_MIS if rng.random() < 0.3 else pt.INTEGRATOR_PATH
     cam = pt.Camera(eye, look, up, w, h, 0, 0, fov)
     out = {}
-    for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING, pt.VARIANT_STEALING + 10 + int(rng.integers(1, 6))):
+    # + 2 / + 3: single paths / whole pixel-iterations change hands; + 10 + k: k + 1 iteration ranges
+    for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING, pt.VARIANT_STEALING + 2, pt.VARIANT_STEALING + 3,
+                    pt.VARIANT_STEALING + 10 + int(rng.integers(1, 6))):
         tr = pt.Pathtracer(cam, depth, seed)
         tr.Init(mats, sph, lights)
         tr.SetAccel(accel)
