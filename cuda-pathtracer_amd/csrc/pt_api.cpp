@@ -42,9 +42,10 @@ struct pt_context {
     int accel;            // PT_ACCEL_*
     // misc device state
     unsigned long long *d_ray_counter;
-    float *d_steal;            // scratch of the work-stealing megakernel, allocated on first use
-    size_t steal_capacity;     // in pixels
+    void *d_steal;             // scratch pool of the work-stealing megakernel + its occupancy bits, allocated on first use
+    bool steal_alloc_failed;   // the pool could not be allocated: render without stealing, do not try again
     bool steal;                // work stealing inside the wave where the kernel supports it
+    uint64_t memory_limit;     // pt_set_memory_limit: bytes of device memory the library may allocate; 0 = no limit
     uint32_t *d_tickets;       // chunked launches: start-order counter + one progress word per tile
     size_t tickets_capacity;   // in words
     int chunks;                // 0: chosen per launch; n: iteration ranges per launch (experiments)
@@ -161,8 +162,9 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->accel = PT_ACCEL_AUTO;
     h->d_ray_counter = nullptr;
     h->d_steal = nullptr;
-    h->steal_capacity = 0;
+    h->steal_alloc_failed = false;
     h->steal = true;           // PT_VARIANT_AUTO
+    h->memory_limit = 0;
     h->d_tickets = nullptr;
     h->tickets_capacity = 0;
     h->chunks = 0;
@@ -333,22 +335,30 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
         float tbits, pbits;
         memcpy(&tbits, &type, 4);
         memcpy(&pbits, &lights[i].u.prim_id, 4);
+        // a light of any other type samples to black (scene.h:169) and keeps only its type here:
+        // the device never reads a position or a sphere index out of it
         light_geom[i] = type == PT_AREA_LIGHT ? make_float4(pbits, 0.f, 0.f, tbits)
-                                              : make_float4(lights[i].u.pos[0], lights[i].u.pos[1], lights[i].u.pos[2], tbits);
+                      : type == PT_POINT_LIGHT ? make_float4(lights[i].u.pos[0], lights[i].u.pos[1], lights[i].u.pos[2], tbits)
+                                               : make_float4(0.f, 0.f, 0.f, tbits);
     }
 
-    PT_HIP(h, hipMalloc((void **)&h->d_sph, sph.size() * sizeof(float4)));
-    PT_HIP(h, hipMalloc((void **)&h->d_aux, aux.size() * sizeof(float4)));
-    PT_HIP(h, hipMalloc((void **)&h->d_mat, mat.size() * sizeof(float4)));
-    PT_HIP(h, hipMalloc((void **)&h->d_light, light.size() * sizeof(float4)));
-    PT_HIP(h, hipMalloc((void **)&h->d_mat_type, mtype.size() * sizeof(int)));
-    PT_HIP(h, hipMalloc((void **)&h->d_light_geom, light_geom.size() * sizeof(float4)));
-    PT_HIP(h, hipMemcpy(h->d_light_geom, light_geom.data(), light_geom.size() * sizeof(float4), hipMemcpyHostToDevice));
-    PT_HIP(h, hipMemcpy(h->d_sph, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice));
-    PT_HIP(h, hipMemcpy(h->d_aux, aux.data(), aux.size() * sizeof(float4), hipMemcpyHostToDevice));
-    PT_HIP(h, hipMemcpy(h->d_mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
-    PT_HIP(h, hipMemcpy(h->d_light, light.data(), light.size() * sizeof(float4), hipMemcpyHostToDevice));
-    PT_HIP(h, hipMemcpy(h->d_mat_type, mtype.data(), mtype.size() * sizeof(int), hipMemcpyHostToDevice));
+    // a failure half-way leaves no partial scene behind
+    auto upload = [](auto **dst, const auto &src) -> hipError_t {
+        const size_t bytes = src.size() * sizeof(src[0]);
+        hipError_t e = hipMalloc((void **)dst, bytes);
+        return e != hipSuccess ? e : hipMemcpy(*dst, src.data(), bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t ue = upload(&h->d_sph, sph);
+    if (ue == hipSuccess) ue = upload(&h->d_aux, aux);
+    if (ue == hipSuccess) ue = upload(&h->d_mat, mat);
+    if (ue == hipSuccess) ue = upload(&h->d_light, light);
+    if (ue == hipSuccess) ue = upload(&h->d_mat_type, mtype);
+    if (ue == hipSuccess) ue = upload(&h->d_light_geom, light_geom);
+    if (ue != hipSuccess) {
+        free_scene(h);
+        return fail(h, ue == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_DEVICE, "pt_init_scene: scene upload failed: %s",
+                    hipGetErrorString(ue));
+    }
     h->n_prims = n_spheres; h->n_mats = n_materials; h->n_lights = n_lights;
     if (n_spheres > kBvhMinSpheres) {
         const int rc = upload_bvh(h, sph, spheres, n_spheres);
@@ -560,41 +570,59 @@ static uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // Paths per wavefront batch the queues are sized for (about 4 GiB of queues + radiance).
 static const uint64_t kWfTargetPaths = 32ull << 20;
+// Device memory per path of a wavefront batch: two queues of 56-byte path records + the path's radiance.
+static const uint64_t kWfBytesPerPath = 2 * (3 * sizeof(float4) + sizeof(uint2)) + 3 * sizeof(float);
 
-// Wavefront variant: batches of whole iterations; per batch one launch per bounce + a resolve.
-static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
+// Iterations per wavefront batch of a frame with `paths_per_it` paths per iteration, within the
+// handle's memory limit; 0 when not even one iteration fits.
+static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_per_it, uint32_t n_iterations)
 {
-    if (h->band_world > 1) return fail(h, PT_ERR_STATE, "the wavefront variant does not support row bands");
-    const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
-    if (h->iteration + (uint64_t)n_iterations >= (1u << 30))
-        return fail(h, PT_ERR_INVALID, "wavefront variant: iteration numbers must stay below 2^30");
-    uint32_t batch_it = (uint32_t)(kWfTargetPaths / paths_per_it);
-    if (batch_it < 1) batch_it = 1;
+    uint64_t target = kWfTargetPaths;
+    if (h->memory_limit && h->memory_limit / kWfBytesPerPath < target) target = h->memory_limit / kWfBytesPerPath;
+    uint64_t batch_it = target / paths_per_it;
+    if (batch_it < 1) batch_it = h->memory_limit ? 0 : 1;
     if (batch_it > n_iterations) batch_it = n_iterations;
-    const uint64_t capacity = paths_per_it * batch_it;
+    return (uint32_t)batch_it;
+}
+
+// Queues, per-path radiance and counters for batches of `capacity` paths (kept while they suffice).
+// A failed allocation frees what was allocated and reports PT_ERR_NOMEM.
+static int ensure_wavefront(pt_context *h, uint64_t capacity, uint32_t *sub_capacity, size_t *counts_bytes_out)
+{
     const uint64_t blocks = (capacity + 255) / 256;
     const uint64_t sub_cap64 = (blocks + kWfSubQueues - 1) / kWfSubQueues * 256;
     if (sub_cap64 > 0xffffff00ull) return fail(h, PT_ERR_INVALID, "wavefront variant: image too large");
     const uint32_t sub_cap = (uint32_t)sub_cap64;
     const size_t counts_bytes = (size_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
-
+    *counts_bytes_out = counts_bytes;
     if (capacity > h->wf_capacity || sub_cap > h->wf_sub_capacity || !h->wf_counts) {
         PT_HIP(h, hipStreamSynchronize(h->stream));
         free_wavefront(h);
         const size_t slots = (size_t)sub_cap * kWfSubQueues;
-        for (int i = 0; i < 2; ++i) {
-            PT_HIP(h, hipMalloc((void **)&h->wf_queue[i].a, slots * sizeof(float4)));
-            PT_HIP(h, hipMalloc((void **)&h->wf_queue[i].b, slots * sizeof(float4)));
-            PT_HIP(h, hipMalloc((void **)&h->wf_queue[i].c, slots * sizeof(float4)));
-            PT_HIP(h, hipMalloc((void **)&h->wf_queue[i].path, slots * sizeof(uint2)));
+        bool ok = true;
+        for (int i = 0; i < 2 && ok; ++i) {
+            ok = hipMalloc((void **)&h->wf_queue[i].a, slots * sizeof(float4)) == hipSuccess &&
+                 hipMalloc((void **)&h->wf_queue[i].b, slots * sizeof(float4)) == hipSuccess &&
+                 hipMalloc((void **)&h->wf_queue[i].c, slots * sizeof(float4)) == hipSuccess &&
+                 hipMalloc((void **)&h->wf_queue[i].path, slots * sizeof(uint2)) == hipSuccess;
         }
-        PT_HIP(h, hipMalloc((void **)&h->wf_radiance, capacity * 3 * sizeof(float)));
-        PT_HIP(h, hipMalloc((void **)&h->wf_counts, counts_bytes));
+        ok = ok && hipMalloc((void **)&h->wf_radiance, capacity * 3 * sizeof(float)) == hipSuccess &&
+             hipMalloc((void **)&h->wf_counts, counts_bytes) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            free_wavefront(h);
+            return fail(h, PT_ERR_NOMEM, "wavefront variant: cannot allocate queues for %llu paths (%llu MiB)",
+                        (unsigned long long)capacity, (unsigned long long)(capacity * kWfBytesPerPath >> 20));
+        }
         h->wf_capacity = capacity;
         h->wf_sub_capacity = sub_cap;
     }
+    *sub_capacity = h->wf_sub_capacity;
+    return PT_OK;
+}
 
-    WavefrontParams p;
+static void fill_wavefront(const pt_context *h, WavefrontParams &p)
+{
     memset(&p, 0, sizeof p);
     fill_camera(h, p.cam);
     fill_scene(h, p.scene);
@@ -604,10 +632,46 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
     p.sub_capacity = h->wf_sub_capacity;
     p.counts = h->wf_counts;
     p.path_radiance = h->wf_radiance;
+    p.x0 = 0; p.y0 = 0; p.rect_w = p.cam.width; p.rect_h = p.cam.height;
+}
+
+// One batch: a launch per bounce over the compacted queues, then the resolve.
+static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, size_t counts_bytes)
+{
+    const bool tiled = scene_streams(p.scene);
+    PT_HIP(h, hipMemsetAsync(h->wf_counts, 0, counts_bytes, h->stream));
+    for (int b = 0; b <= h->max_bounces; ++b) {
+        p.bounce = b;
+        p.out = h->wf_queue[b & 1];
+        p.in = h->wf_queue[(b & 1) ^ 1];
+        PT_HIP(h, launch_wavefront_step(p, tiled, h->stream));
+    }
+    PT_HIP(h, launch_wavefront_resolve(p, h->stream));
+    return PT_OK;
+}
+
+// Wavefront variant: batches of whole iterations; per batch one launch per bounce + a resolve.
+// Returns PT_ERR_NOMEM (nothing rendered, nothing held) when the queues do not fit.
+static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
+{
+    if (h->band_world > 1) return fail(h, PT_ERR_STATE, "the wavefront variant does not support row bands");
+    const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
+    if (h->iteration + (uint64_t)n_iterations >= (1u << 30))
+        return fail(h, PT_ERR_INVALID, "wavefront variant: iteration numbers must stay below 2^30");
+    const uint32_t batch_it = wavefront_batch_iterations(h, paths_per_it, n_iterations);
+    if (batch_it == 0)
+        return fail(h, PT_ERR_NOMEM, "wavefront variant: one iteration needs %llu MiB of queues, the memory limit is %llu MiB",
+                    (unsigned long long)(paths_per_it * kWfBytesPerPath >> 20), (unsigned long long)(h->memory_limit >> 20));
+    uint32_t sub_cap = 0;
+    size_t counts_bytes = 0;
+    const int rc = ensure_wavefront(h, paths_per_it * batch_it, &sub_cap, &counts_bytes);
+    if (rc != PT_OK) return rc;
+
+    WavefrontParams p;
+    fill_wavefront(h, p);
     p.accum_mode = h->accum_mode;
     p.buffer = dbuf;
     p.ray_counter = h->d_ray_counter;
-    const bool tiled = scene_streams(p.scene);
 
     PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
     uint32_t done = 0;
@@ -617,14 +681,8 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
         p.n_iterations = n;
         p.overwrite = h->accum_mode == PT_ACCUM_RUNNING_MEAN ? (p.first_iteration == 1)
                                                              : ((h->fresh && done == 0) ? 1 : 0);
-        PT_HIP(h, hipMemsetAsync(h->wf_counts, 0, counts_bytes, h->stream));
-        for (int b = 0; b <= h->max_bounces; ++b) {
-            p.bounce = b;
-            p.out = h->wf_queue[b & 1];
-            p.in = h->wf_queue[(b & 1) ^ 1];
-            PT_HIP(h, launch_wavefront_step(p, tiled, h->stream));
-        }
-        PT_HIP(h, launch_wavefront_resolve(p, h->stream));
+        const int brc = launch_wavefront_batch(h, p, counts_bytes);
+        if (brc != PT_OK) return brc;
         done += n;
     }
     PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
@@ -649,22 +707,91 @@ static uint32_t auto_chunks(uint64_t tiles, uint32_t n_iterations)
     return n < 1 ? 1u : (uint32_t)n;
 }
 
-// Enqueue n iterations on the handle's stream.
-static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
+// Does this render go through the per-bounce wavefront launches?  Explicitly selected, or
+// PT_VARIANT_AUTO on a BVH scene: BVH traversals differ so much in length that the queue-fed
+// persistent waves are twice as fast as the megakernel (measured); everything else stays with
+// the megakernel.
+static bool takes_wavefront(const pt_context *h, uint64_t last_iteration)
 {
-    if (!h->scene_ready) return fail(h, PT_ERR_STATE, "render before pt_init_scene");
-    if (!dbuf) return fail(h, PT_ERR_INVALID, "render: buffer is NULL");
-    if (n_iterations == 0) return PT_OK;
-    if (h->iteration > 0xffffffffu - n_iterations) return fail(h, PT_ERR_INVALID, "iteration counter overflow");
-    if (h->wavefront && h->integrator != PT_INTEGRATOR_PATH)
-        return fail(h, PT_ERR_STATE, "the wavefront variant only implements PT_INTEGRATOR_PATH");
-    if (h->wavefront) return enqueue_wavefront(h, dbuf, n_iterations);
-    // PT_VARIANT_AUTO: BVH traversals differ so much in length that the queue-fed persistent waves
-    // are twice as fast as the megakernel (measured); everything else stays with the megakernel.
-    if (h->auto_variant && h->accel == PT_ACCEL_AUTO && h->bvh.n_nodes > 0 && h->band_world == 1 &&
-        h->integrator == PT_INTEGRATOR_PATH && h->iteration + (uint64_t)n_iterations < (1u << 30))
-        return enqueue_wavefront(h, dbuf, n_iterations);
+    if (h->wavefront) return true;
+    return h->auto_variant && h->accel == PT_ACCEL_AUTO && h->bvh.n_nodes > 0 && h->band_world == 1 &&
+           h->integrator == PT_INTEGRATOR_PATH && last_iteration < (1u << 30);
+}
 
+// The handle's own scratch of the work-stealing megakernel (pool + occupancy bits in one
+// allocation), allocated on first use; false when it cannot be had (the launch then does not steal).
+static bool own_steal_scratch(pt_context *h, StealScratch *out)
+{
+    if (!h->d_steal && !h->steal_alloc_failed) {
+        const size_t bytes = kStealPoolBytes + kStealMaskBytes;
+        if ((h->memory_limit && bytes > h->memory_limit) || hipMalloc(&h->d_steal, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            h->d_steal = nullptr;
+            h->steal_alloc_failed = true;
+        } else if (hipMemsetAsync((unsigned char *)h->d_steal + kStealPoolBytes, 0, kStealMaskBytes, h->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(h->d_steal);
+            h->d_steal = nullptr;
+            h->steal_alloc_failed = true;
+        }
+    }
+    if (!h->d_steal) return false;
+    out->pool = (float *)h->d_steal;
+    out->mask = (unsigned long long *)((unsigned char *)h->d_steal + kStealPoolBytes);
+    out->tickets = h->d_tickets;
+    out->ticket_words = (uint32_t)(h->tickets_capacity > 0xffffffffu ? 0xffffffffu : h->tickets_capacity);
+    return true;
+}
+
+// Work stealing and iteration ranges of a megakernel launch of grid_x x grid_y tiles.
+// fixed == NULL: the handle's own scratch, allocated (and its ticket array grown) as needed;
+// else the statically allocated scratch: nothing is allocated, its occupancy bits and tickets are
+// cleared on the stream first.
+static int setup_steal(pt_context *h, RenderParams &p, uint32_t grid_x, uint32_t grid_y, uint32_t n_iterations,
+                       const StealScratch *fixed)
+{
+    if (!h->steal || n_iterations >= (1u << 30)) return PT_OK;
+    StealScratch sc;
+    if (fixed) sc = *fixed;
+    else if (!own_steal_scratch(h, &sc)) return PT_OK;
+    p.steal_scratch = sc.pool;
+    p.steal_mask = sc.mask;
+    // chunked launch: more, shorter workgroups (see render_steal_kernel)
+    uint32_t n_chunks = h->chunks > 0 ? (uint32_t)h->chunks : auto_chunks((uint64_t)grid_x * grid_y, n_iterations);
+    if (n_chunks > n_iterations / 4) n_chunks = n_iterations / 4;   // ranges of at least 4 iterations
+    if (n_chunks > 1) n_chunks = div_up(n_iterations, div_up(n_iterations, n_chunks));   // no empty range
+    if (n_chunks > 1 && (uint64_t)grid_y * n_chunks > 65535u) n_chunks = 1;
+    const size_t words = 1 + (size_t)grid_x * grid_y;
+    if (!fixed && n_chunks > 1 && words > h->tickets_capacity) {
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->d_tickets) (void)hipFree(h->d_tickets);
+        h->d_tickets = nullptr; h->tickets_capacity = 0;
+        // without the tickets the launch is simply not cut into ranges
+        if (hipMalloc((void **)&h->d_tickets, words * sizeof(uint32_t)) == hipSuccess)
+            h->tickets_capacity = words;
+        else
+            (void)hipGetLastError();
+        sc.tickets = h->d_tickets;
+        sc.ticket_words = (uint32_t)h->tickets_capacity;
+    }
+    if (fixed)   // contents of the last call: the bits must start at zero, and so must the tickets
+        PT_HIP(h, hipMemsetAsync(sc.mask, 0, kStealMaskBytes + (n_chunks > 1 ? words * sizeof(uint32_t) : 0), h->stream));
+    if (n_chunks > 1 && sc.tickets && words <= sc.ticket_words) {
+        if (!fixed) PT_HIP(h, hipMemsetAsync(sc.tickets, 0, words * sizeof(uint32_t), h->stream));
+        p.n_chunks = n_chunks;
+        p.tickets = sc.tickets;
+    }
+    // Launches (ranges) of a few iterations: lanes have too few whole iterations to give away,
+    // single paths change hands instead (measured at 1080p, demo scene: 1 iteration per
+    // launch +23 %, 2: +18 %, 4: +7 %, 8: -3 %).
+    const uint32_t per_range = div_up(n_iterations, p.n_chunks > 1 ? p.n_chunks : 1u);
+    p.steal_unit = h->steal_unit ? h->steal_unit : (per_range <= 5 ? 1 : 4);
+    return PT_OK;
+}
+
+// Enqueue n iterations of the megakernel on the handle's stream.
+static int enqueue_megakernel(pt_context *h, float *dbuf, uint32_t n_iterations, const StealScratch *fixed)
+{
     RenderParams p;
     fill_params(h, p);
     p.x0 = 0; p.y0 = 0; p.x1 = p.cam.width; p.y1 = p.cam.height;
@@ -687,61 +814,37 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
     }
     const bool tiled = scene_streams(p.scene);
     if (grid_y > 0) {
-        // scratch of the work-stealing kernel: 96 bytes per pixel, at most 4 GiB (larger frames render
-        // without stealing)
-        const size_t pixels = (size_t)p.cam.width * p.cam.height;
-        const bool scratch_fits = pixels * kStealSlots * 3 * sizeof(float) <= ((size_t)4 << 30);
-        if (h->steal && scratch_fits && n_iterations < (1u << 30)) {
-            if (pixels > h->steal_capacity) {
-                PT_HIP(h, hipStreamSynchronize(h->stream));
-                if (h->d_steal) (void)hipFree(h->d_steal);
-                h->d_steal = nullptr; h->steal_capacity = 0;
-                // without the scratch the launch simply does not steal
-                if (hipMalloc((void **)&h->d_steal, pixels * kStealSlots * 3 * sizeof(float)) == hipSuccess)
-                    h->steal_capacity = pixels;
-                else
-                    (void)hipGetLastError();
-            }
-            p.steal_scratch = h->d_steal;
-            // chunked launch: more, shorter workgroups (see render_steal_kernel)
-            const uint32_t grid_x = div_up(p.cam.width, 16);
-            uint32_t n_chunks = h->chunks > 0 ? (uint32_t)h->chunks : auto_chunks((uint64_t)grid_x * grid_y, n_iterations);
-            if (n_chunks > n_iterations / 4) n_chunks = n_iterations / 4;   // ranges of at least 4 iterations
-            if (n_chunks > 1) n_chunks = div_up(n_iterations, div_up(n_iterations, n_chunks));   // no empty range
-            if (n_chunks > 1 && (uint64_t)grid_y * n_chunks > 65535u) n_chunks = 1;
-            const size_t words = 1 + (size_t)grid_x * grid_y;
-            if (n_chunks > 1 && p.steal_scratch && words > h->tickets_capacity) {
-                PT_HIP(h, hipStreamSynchronize(h->stream));
-                if (h->d_tickets) (void)hipFree(h->d_tickets);
-                h->d_tickets = nullptr; h->tickets_capacity = 0;
-                // without the tickets the launch is simply not cut into ranges
-                if (hipMalloc((void **)&h->d_tickets, words * sizeof(uint32_t)) == hipSuccess)
-                    h->tickets_capacity = words;
-                else
-                    (void)hipGetLastError();
-            }
-            if (n_chunks > 1 && p.steal_scratch && words <= h->tickets_capacity) {
-                PT_HIP(h, hipMemsetAsync(h->d_tickets, 0, words * sizeof(uint32_t), h->stream));
-                p.n_chunks = n_chunks;
-                p.tickets = h->d_tickets;
-            }
-            // Launches (ranges) of a few iterations: lanes have too few whole iterations to give away,
-            // single paths change hands instead (measured at 1080p, demo scene: 1 iteration per
-            // launch +23 %, 2: +18 %, 4: +7 %, 8: -3 %).
-            const uint32_t per_range = div_up(n_iterations, p.n_chunks > 1 ? p.n_chunks : 1u);
-            p.steal_unit = h->steal_unit ? h->steal_unit : (per_range <= 5 ? 1 : 4);
-        }
+        const uint32_t grid_x = div_up(p.cam.width, 16);
+        const int rc = setup_steal(h, p, grid_x, grid_y, n_iterations, fixed);
+        if (rc != PT_OK) return rc;
         PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
         if (h->integrator == PT_INTEGRATOR_NEE_MIS)
-            PT_HIP(h, launch_render_nee(p, div_up(p.cam.width, 16), grid_y, tiled, false, h->stream));
+            PT_HIP(h, launch_render_nee(p, grid_x, grid_y, tiled, false, h->stream));
         else
-            PT_HIP(h, launch_render(p, div_up(p.cam.width, 16), grid_y, tiled, false, h->stream));
+            PT_HIP(h, launch_render(p, grid_x, grid_y, tiled, false, h->stream));
         PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
         h->timed = true;
     }
     h->iteration += n_iterations;
     h->fresh = false;
     return PT_OK;
+}
+
+// Enqueue n iterations on the handle's stream.
+static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
+{
+    if (!h->scene_ready) return fail(h, PT_ERR_STATE, "render before pt_init_scene");
+    if (!dbuf) return fail(h, PT_ERR_INVALID, "render: buffer is NULL");
+    if (n_iterations == 0) return PT_OK;
+    if (h->iteration > 0xffffffffu - n_iterations) return fail(h, PT_ERR_INVALID, "iteration counter overflow");
+    if (h->wavefront && h->integrator != PT_INTEGRATOR_PATH)
+        return fail(h, PT_ERR_STATE, "the wavefront variant only implements PT_INTEGRATOR_PATH");
+    if (takes_wavefront(h, h->iteration + (uint64_t)n_iterations)) {
+        const int rc = enqueue_wavefront(h, dbuf, n_iterations);
+        // PT_VARIANT_AUTO: when the queues cannot be had the megakernel renders the same image
+        if (rc != PT_ERR_NOMEM || h->wavefront) return rc;
+    }
+    return enqueue_megakernel(h, dbuf, n_iterations, nullptr);
 }
 
 int pt_run_n(pt_handle h, float *device_buffer, uint32_t n_iterations, int sync)
@@ -914,7 +1017,28 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
     if (pixel_rgb) DBG_HIP(hipMalloc((void **)&d_rgb, n_pix * 3 * sizeof(float)));
     DBG_HIP(hipMalloc((void **)&d_cnt, sizeof(unsigned long long)));
     DBG_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
-    {
+    // The rectangle goes through the kernels a render of this instance would use: the per-bounce
+    // wavefront launches, the work-stealing megakernel, or the plain one.
+    if (takes_wavefront(h, iteration) && h->integrator == PT_INTEGRATOR_PATH && iteration < (1u << 30)) {
+        uint32_t sub_cap = 0;
+        size_t counts_bytes = 0;
+        rc = ensure_wavefront(h, n_paths, &sub_cap, &counts_bytes);
+        if (rc != PT_OK) goto cleanup;
+        WavefrontParams p;
+        fill_wavefront(h, p);
+        p.x0 = x0; p.y0 = y0; p.rect_w = x1 - x0; p.rect_h = y1 - y0;
+        p.first_iteration = iteration;
+        p.n_iterations = 1;
+        p.accum_mode = PT_ACCUM_SUM;
+        p.overwrite = 1;
+        p.buffer = nullptr;
+        p.ray_counter = d_cnt;
+        p.hit_ids = d_hits; p.pixel_rgb = d_rgb;
+        rc = launch_wavefront_batch(h, p, counts_bytes);
+        if (rc != PT_OK) goto cleanup;
+        // the batch's per-path radiance buffer has the layout of `radiance`
+        if (radiance) DBG_HIP(hipMemcpyAsync(radiance, h->wf_radiance, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    } else {
         RenderParams p;
         fill_params(h, p);
         p.x0 = x0; p.y0 = y0; p.x1 = x1; p.y1 = y1;
@@ -927,13 +1051,15 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
         p.ray_counter = d_cnt;
         p.hit_ids = d_hits; p.path_rad = d_rad; p.pixel_rgb = d_rgb;
         const bool tiled = scene_streams(p.scene);
+        rc = setup_steal(h, p, div_up(x1 - x0, 16), p.band_rows / 16, 1, nullptr);
+        if (rc != PT_OK) goto cleanup;
         if (h->integrator == PT_INTEGRATOR_NEE_MIS)
             DBG_HIP(launch_render_nee(p, div_up(x1 - x0, 16), p.band_rows / 16, tiled, true, h->stream));
         else
             DBG_HIP(launch_render(p, div_up(x1 - x0, 16), p.band_rows / 16, tiled, true, h->stream));
+        if (radiance) DBG_HIP(hipMemcpyAsync(radiance, d_rad, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     }
     if (hit_ids) DBG_HIP(hipMemcpyAsync(hit_ids, d_hits, hit_elems * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    if (radiance) DBG_HIP(hipMemcpyAsync(radiance, d_rad, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     if (pixel_rgb) DBG_HIP(hipMemcpyAsync(pixel_rgb, d_rgb, n_pix * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     {
         unsigned long long cnt = 0;

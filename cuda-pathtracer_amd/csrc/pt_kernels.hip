@@ -175,6 +175,52 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
     if (lane == 0 && p.ray_counter && total) atomicAdd(p.ray_counter, (unsigned long long)total);
 }
 
+// ---- scratch blocks of the work-stealing megakernel --------------------------------------------------
+// Takes a free block of the pool (layout: pt_kernels.hpp) for the calling workgroup, from the
+// sub-pool of the XCD it runs on: a block is then only ever read and written through that XCD's
+// L2, so what a workgroup left in it needs no write-back before the next one may use it.
+// Returns kNoStealBlock when the sub-pool has no free block (the workgroup then does not steal);
+// bounded: at most four words are tried, each until it is full.
+constexpr uint32_t kNoStealBlock = 0xffffffffu;
+
+PT_DEV uint32_t steal_block_acquire(unsigned long long *mask, uint32_t hint)
+{
+    // XCC_ID (hardware register 20), bits 3:0: the XCD this wave runs on
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & (kStealPoolXcc - 1u);
+    unsigned long long *m = mask + xcc * kStealMaskWordsPerXcc;
+    const uint32_t rot = (hint >> 2) & 63u;   // workgroups that start together try different bits first
+    for (uint32_t k = 0; k < kStealPoolPerXcc / 64u; ++k) {
+        const uint32_t w = (hint + k) & (kStealPoolPerXcc / 64u - 1u);
+        unsigned long long seen = __hip_atomic_load(m + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (~seen) {
+            const unsigned long long avail = ~seen;
+            const unsigned long long rotated = (avail >> rot) | (rot ? avail << (64u - rot) : 0ull);
+            const uint32_t bit = ((uint32_t)__builtin_ctzll(rotated) + rot) & 63u;
+            const unsigned long long b = 1ull << bit;
+            const unsigned long long prev = __hip_atomic_fetch_or(m + w, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(prev & b)) return xcc * kStealPoolPerXcc + w * 64u + bit;
+            seen = prev;
+        }
+    }
+    return kNoStealBlock;
+}
+
+PT_DEV void steal_block_release(unsigned long long *mask, uint32_t block)
+{
+    const uint32_t xcc = block / kStealPoolPerXcc, in = block % kStealPoolPerXcc;
+    __hip_atomic_fetch_and(mask + xcc * kStealMaskWordsPerXcc + (in >> 6), ~(1ull << (in & 63u)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// parity hook: the colour pathtracer.cu:94-101 computes for pixel (x, y) of the traced rectangle
+PT_DEV void record_pixel(const RenderParams &p, uint32_t x, uint32_t y, V3 cpix)
+{
+    if (p.pixel_rgb) {
+        float *pr = p.pixel_rgb + ((size_t)(y - p.y0) * (p.x1 - p.x0) + (x - p.x0)) * 3;
+        pr[0] = cpix.x; pr[1] = cpix.y; pr[2] = cpix.z;
+    }
+}
+
 // ---- megakernel with work stealing inside the wave ---------------------------------------------------
 // render_kernel gives every lane one pixel for the whole launch.  The pixels of a wave need
 // different numbers of bounces, so lanes finish at different times and wait for the slowest one:
@@ -196,13 +242,23 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(const RenderParam
 // Waves per SIMD the register allocation aims at: 5 for the NEE integrator (96 VGPRs), 6 where LDS
 // (camera-ray ring, sphere tile) allows no more anyway, 7 (72 VGPRs, no spills; 8 would spill) for the plain resident scenes: +3 % on the
 // 71-sphere scene.
-template <bool RING, bool TILED, bool NEE, bool BVH, bool UNIT1>
+//
+// RECORD: the parity hook's outputs (hit indices, per-path radiance, pixel colours) are written as
+// well, so that pt_debug_trace reports what THIS kernel computes, stolen paths included.
+template <bool RING, bool TILED, bool NEE, bool BVH, bool UNIT1, bool RECORD>
 __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED) ? 6 : 7))) void render_steal_kernel(const RenderParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ uint32_t s_wg[2];   // start-order ticket, scratch block of this workgroup
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) {
+        s_wg[0] = p.n_chunks > 1 ? atomicAdd(p.tickets, 1u) : 0u;
+        s_wg[1] = p.steal_scratch ? steal_block_acquire(p.steal_mask, blockIdx.y * gridDim.x + blockIdx.x) : kNoStealBlock;
+    }
+    __syncthreads();
+    const uint32_t steal_block = s_wg[1];
 
     // ---- tile and iteration range of this workgroup ------------------------------------------------------
     // Plain launch: the tile is the block index, the workgroup renders all iterations.
@@ -216,12 +272,10 @@ __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED
     uint32_t bx = blockIdx.x, by = blockIdx.y, chunk = 0, tile = 0;
     uint32_t first_it = p.first_iteration, n_it = p.n_iterations;
     if (p.n_chunks > 1) {
-        __shared__ uint32_t s_ticket;
-        if (tid == 0) s_ticket = atomicAdd(p.tickets, 1u);
-        __syncthreads();
+        const uint32_t ticket = s_wg[0];
         const uint32_t n_tiles = gridDim.x * (gridDim.y / p.n_chunks);
-        chunk = s_ticket / n_tiles;
-        tile = s_ticket - chunk * n_tiles;
+        chunk = ticket / n_tiles;
+        tile = ticket - chunk * n_tiles;
         by = tile / gridDim.x;
         bx = tile - by * gridDim.x;
         const uint32_t per = (p.n_iterations + p.n_chunks - 1) / p.n_chunks;   // host: no range is empty
@@ -280,7 +334,9 @@ __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED
     V3 o = cam_pos, d = mk(0.f, 0.f, 1.f), T = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
     int b = 0;
     uint32_t nrays = 0;
-    bool stealing = p.steal_scratch != nullptr;   // wave-uniform; cleared once nothing is left to steal
+    bool stealing = steal_block != kNoStealBlock;   // wave-uniform; cleared once nothing is left to steal
+    // this wave's part of the workgroup's scratch block: [slot][lane of the wave][3]
+    float *const steal_wave = p.steal_scratch + (size_t)(stealing ? steal_block : 0u) * kStealBlockFloats + (size_t)(wave * 64) * 3;
     // NEE + MIS integrator (see render_nee_kernel): a diffuse vertex parks its direct-light term and
     // sends the shadow ray through the next pass's Intersect
     NeeState st;
@@ -388,6 +444,14 @@ __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED
         if (alive) {
             PT_LS(17);
             ++nrays;
+            // parity hook: index of the path in hand within the traced rectangle
+            size_t rec_path = 0;
+            if (RECORD) {
+                const uint32_t from = t_from < 0 ? (uint32_t)lane : (uint32_t)(t_from & 63);
+                const uint32_t tx = wave_x0 + (from & 7u), ty = wave_y0 + (from >> 3);
+                rec_path = ((size_t)(ty - p.y0) * (p.x1 - p.x0) + (tx - p.x0)) * 4 + (tg & 3u);
+                if (p.hit_ids && !shadow) p.hit_ids[rec_path * (size_t)(mb + 1) + b] = best;
+            }
             bool end = true;
             if (shadow) {
                 const bool visible = st.sh_prim >= 0 ? best == st.sh_prim : best < 0;
@@ -406,11 +470,19 @@ __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED
             if (end) {
                 alive = false;
                 const bool last_of_iteration = (tg & 3u) == 3u;
+                if (RECORD) {
+                    if (p.path_rad) {
+                        float *pr = p.path_rad + rec_path * 3;
+                        pr[0] = L.x; pr[1] = L.y; pr[2] = L.z;
+                    }
+                }
                 if (t_from < 0) {
                     // own path: the running sum, and the running mean once the iteration is complete
                     c = c + L;
                     if (last_of_iteration) {
-                        acc = accumulate_pixel(acc, c, tit, p.accum_mode);
+                        V3 cpix;
+                        acc = accumulate_pixel(acc, c, tit, p.accum_mode, &cpix);
+                        if (RECORD) record_pixel(p, x, y, cpix);
                         c = mk(0.f, 0.f, 0.f);
                     }
                     has_task = next_own < own_end;
@@ -424,7 +496,7 @@ __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED
                 } else {
                     // stolen unit complete: leave the 4-path sum, or the path's radiance, for the owner
                     const V3 v = unit == 4u ? c + L : L;
-                    float *slot = p.steal_scratch + ((size_t)tpix * kStealSlots + ((n_paths - tg - 1u) / unit)) * 3;
+                    float *slot = steal_wave + ((size_t)((n_paths - tg - 1u) / unit) * kBlockThreads + (uint32_t)(t_from & 63)) * 3;
                     slot[0] = v.x; slot[1] = v.y; slot[2] = v.z;
                     if (unit == 4u) c = mk(0.f, 0.f, 0.f);
                     has_task = false;   // a thief has no paths of its own left
@@ -439,17 +511,20 @@ __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED
     if (own_end < n_paths && valid) {
         __threadfence_block();   // their results were stored by this same wave
         for (uint32_t g = own_end; g < n_paths; g += unit) {
-            const float *slot = p.steal_scratch + ((size_t)pix * kStealSlots + ((n_paths - g - 1u) / unit)) * 3;
+            const float *slot = steal_wave + ((size_t)((n_paths - g - 1u) / unit) * kBlockThreads + (uint32_t)lane) * 3;
             // read past the vector cache: the line may have been cached before a thief wrote to it
             const V3 v = mk(__hip_atomic_load(slot + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                             __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                             __hip_atomic_load(slot + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            V3 cpix;
             if (unit == 4u) {
-                acc = accumulate_pixel(acc, v, first + (g >> 2), p.accum_mode);
+                acc = accumulate_pixel(acc, v, first + (g >> 2), p.accum_mode, &cpix);
+                if (RECORD) record_pixel(p, x, y, cpix);
             } else {
                 c = c + v;
                 if ((g & 3u) == 3u) {
-                    acc = accumulate_pixel(acc, c, first + (g >> 2), p.accum_mode);
+                    acc = accumulate_pixel(acc, c, first + (g >> 2), p.accum_mode, &cpix);
+                    if (RECORD) record_pixel(p, x, y, cpix);
                     c = mk(0.f, 0.f, 0.f);
                 }
             }
@@ -465,6 +540,11 @@ __global__ __launch_bounds__(kBlockThreads, BVH ? 4 : (NEE ? 5 : ((RING || TILED
         __syncthreads();
         if (tid == 0)
             __hip_atomic_store(p.tickets + 1 + tile, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (steal_block != kNoStealBlock) {
+        // every wave is through with the block (the barrier also waits for their stores to it)
+        __syncthreads();
+        if (tid == 0) steal_block_release(p.steal_mask, steal_block);
     }
     const uint32_t total = wave_sum(nrays);
     if (lane == 0 && p.ray_counter && total) atomicAdd(p.ray_counter, (unsigned long long)total);
@@ -565,7 +645,7 @@ static size_t render_lds_bytes(const SceneParams &s, bool tiled, bool ring)
 
 // The work-stealing megakernel (linear-scan scenes, p.steal_scratch set); nee: the NEE + MIS integrator.
 hipError_t launch_render_steal(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled, bool nee,
-                               hipStream_t stream)
+                               bool record, hipStream_t stream)
 {
     // BVH scenes keep the scene in device memory (TILED staging without the sphere tile) and the
     // per-lane traversal stacks in LDS.
@@ -577,8 +657,13 @@ hipError_t launch_render_steal(const RenderParams &p, uint32_t grid_x, uint32_t 
     const dim3 grid(grid_x, grid_y * (p.n_chunks > 1 ? p.n_chunks : 1u)), block(kBlockThreads);
 #define PT_LAUNCH_STEAL(G, T, N, B)                                                                              \
     do {                                                                                                          \
-        if (p.steal_unit == 1) hipLaunchKernelGGL((render_steal_kernel<G, T, N, B, true>), grid, block, lds, stream, p); \
-        else hipLaunchKernelGGL((render_steal_kernel<G, T, N, B, false>), grid, block, lds, stream, p);           \
+        if (record) {                                                                                             \
+            if (p.steal_unit == 1) hipLaunchKernelGGL((render_steal_kernel<G, T, N, B, true, true>), grid, block, lds, stream, p); \
+            else hipLaunchKernelGGL((render_steal_kernel<G, T, N, B, false, true>), grid, block, lds, stream, p);  \
+        } else {                                                                                                  \
+            if (p.steal_unit == 1) hipLaunchKernelGGL((render_steal_kernel<G, T, N, B, true, false>), grid, block, lds, stream, p); \
+            else hipLaunchKernelGGL((render_steal_kernel<G, T, N, B, false, false>), grid, block, lds, stream, p); \
+        }                                                                                                         \
     } while (0)
     if (bvh) {
         if (nee) PT_LAUNCH_STEAL(false, true, true, true); else PT_LAUNCH_STEAL(false, true, false, true);
@@ -600,7 +685,7 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y
     const bool ring = !tiled && p.scene.n_prims <= kMaxRingSpheres && (p.small_scene_opts & 1);
     const bool bvh = p.scene.bvh.n_nodes > 0;   // BVH kernels read the scene from global memory
     // Work stealing inside the wave: linear-scan scenes (staged in LDS or streamed), plain renders, regeneration on
-    if (p.steal_scratch && !record && p.regen_min_idle <= 1) return launch_render_steal(p, grid_x, grid_y, tiled, false, stream);
+    if (p.steal_scratch && p.regen_min_idle <= 1) return launch_render_steal(p, grid_x, grid_y, tiled, false, record, stream);
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : render_lds_bytes(p.scene, tiled, ring);
 #define PT_LAUNCH(T, R, G, B) hipLaunchKernelGGL((render_kernel<T, R, G, B>), grid, block, lds, stream, p)
     if (bvh) {

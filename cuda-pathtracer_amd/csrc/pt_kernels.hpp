@@ -23,11 +23,33 @@ constexpr uint32_t kBvhMinSpheres = 192;
 constexpr uint32_t kMaxRingSpheres = 24;
 // Work stealing inside the wave: iterations per pixel and launch that other lanes may take over.
 constexpr uint32_t kStealSlots = 8;
+// Scratch of the work-stealing megakernel.  A stolen unit's result only lives until the wave that
+// produced it ends, so the scratch is a pool of per-workgroup blocks, sized by the workgroups the
+// chip can hold at once and not by the frame: kStealPoolXcc sub-pools (one per XCD, so that a block
+// is only ever touched through one L2) of kStealPoolPerXcc blocks (32 CUs x 8 workgroups of four
+// waves), each [kStealSlots][256 lanes][3] floats.  A workgroup takes a free block of its XCD's
+// sub-pool when it starts (one bit per block in `mask`) and returns it when it ends; a workgroup
+// that finds none renders without stealing.
+constexpr uint32_t kStealPoolXcc = 8;
+constexpr uint32_t kStealPoolPerXcc = 256;
+constexpr uint32_t kStealBlockFloats = kStealSlots * 256 * 3;
+constexpr size_t kStealPoolBytes = (size_t)kStealPoolXcc * kStealPoolPerXcc * kStealBlockFloats * sizeof(float);   // 48 MiB
+// occupancy bits of the pool: per XCD one 128-byte line, of which the first 256 bits are used
+constexpr uint32_t kStealMaskWordsPerXcc = 16;
+constexpr size_t kStealMaskBytes = (size_t)kStealPoolXcc * kStealMaskWordsPerXcc * sizeof(unsigned long long);     // 1 KiB
 
 // What Camera::GenerateRay reads (camera.h:66-72).
 struct CameraParams {
     float pos[3], pxx[3], pxy[3], first[3];
     uint32_t width, height;
+};
+
+// Where a launch of the work-stealing megakernel finds its scratch.
+struct StealScratch {
+    float *pool;                  // kStealPoolBytes
+    unsigned long long *mask;     // kStealMaskBytes
+    uint32_t *tickets;            // iteration ranges: start-order counter + one word per tile (may be NULL)
+    uint32_t ticket_words;
 };
 
 // Sphere BVH in device memory (layout: pt_bvh.hpp); n_nodes == 0 when there is none.
@@ -73,9 +95,11 @@ struct RenderParams {
     int overwrite;            // 1: start from zero instead of reading the buffer
     int regen_min_idle;       // 1..64, idle lanes needed before a wave starts new paths
     int small_scene_opts;     // bit 0: camera-ray ring (scenes <= kMaxRingSpheres)
-    // work stealing inside the wave (render_steal_kernel): [width*height][kStealSlots][3] floats of
-    // scratch for the pixel-iterations rendered by another lane than the pixel's; NULL: no stealing
+    // work stealing inside the wave (render_steal_kernel): the pool of per-workgroup scratch blocks
+    // (kStealPoolBytes) for the units rendered by another lane than the pixel's, and its occupancy
+    // bits (kStealMaskBytes, all zero between launches); NULL: no stealing
     float *steal_scratch;
+    unsigned long long *steal_mask;
     int steal_unit;           // paths that change hands at a time: 4 (a pixel-iteration) or 1
     // chunked launch of render_steal_kernel: n_chunks consecutive iteration ranges, one workgroup per
     // tile and range; tickets[0] = start-order counter, tickets[1 + tile] = ranges of the tile done
@@ -101,7 +125,7 @@ hipError_t read_lane_stats(unsigned long long out[64]);
 hipError_t add_lane_stats_wavefront(unsigned long long out[64]);
 
 hipError_t launch_render_steal(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled, bool nee,
-                               hipStream_t stream);
+                               bool record, hipStream_t stream);
 
 // The opt-in NEE + MIS integrator (pt_nee.hip); same launch geometry.
 hipError_t launch_render_nee(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled, bool record,
@@ -126,6 +150,7 @@ struct WavefrontParams {
     SceneParams scene;
     uint64_t seed;
     int max_bounces;
+    uint32_t x0, y0, rect_w, rect_h;   // pixel rectangle of the batch (a render: the whole frame)
     uint32_t first_iteration;   // of the batch
     uint32_t n_iterations;      // in the batch
     int bounce;                 // bounce index handled by this launch
@@ -139,8 +164,11 @@ struct WavefrontParams {
     float *path_radiance;       // [paths][3]
     // resolve
     int accum_mode, overwrite;
-    float *buffer;
+    float *buffer;              // may be NULL (parity hook)
     unsigned long long *ray_counter;
+    // parity hook (NULL in renders): [path of the batch][max_bounces + 1] hit indices, [pixel][3] colours
+    int32_t *hit_ids;
+    float *pixel_rgb;
 };
 
 hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream_t stream);

@@ -138,7 +138,7 @@ hipError_t launch_render_nee(const RenderParams &p, uint32_t grid_x, uint32_t gr
     const dim3 grid(grid_x, grid_y), block(kBlockThreads);
     const bool bvh = p.scene.bvh.n_nodes > 0;   // BVH kernels read the scene from global memory
     // plain renders: the work-stealing megakernel (pt_kernels.hip)
-    if (p.steal_scratch && !record && p.regen_min_idle <= 1) return launch_render_steal(p, grid_x, grid_y, tiled, true, stream);
+    if (p.steal_scratch && p.regen_min_idle <= 1) return launch_render_steal(p, grid_x, grid_y, tiled, true, record, stream);
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : scene_lds_bytes(p.scene, tiled);
 #define PT_LAUNCH(T, R, B) hipLaunchKernelGGL((render_nee_kernel<T, R, B>), grid, block, lds, stream, p)
     if (bvh) {

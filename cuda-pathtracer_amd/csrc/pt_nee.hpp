@@ -214,8 +214,13 @@ PT_DEV bool shade_bounce_nee(const SceneParams &sp, const SceneView &sc, float4 
         V3 wl, li;
         float pdf_l;
         Segment seg;
-        const bool point = __float_as_int(lg.w) == 0;
-        if (point) {
+        const int ltype = __float_as_int(lg.w);
+        const bool point = ltype == 0;
+        if (ltype != 0 && ltype != 1) {
+            // SampleLight, scene.h:169: a light of unknown type contributes nothing
+            wl = mk(0.f, 0.f, 1.f); li = mk(0.f, 0.f, 0.f); pdf_l = 0.f;
+            seg.d = wl; seg.maxt = 0.f;
+        } else if (point) {
             // SampleLight, scene.h:153-158
             const V3 pos = mk(lg.x, lg.y, lg.z);
             wl = normalize(pos - P);

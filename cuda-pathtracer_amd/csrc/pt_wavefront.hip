@@ -14,6 +14,8 @@
 // sub-queue q stay in sub-queue q, hence no sub-queue can outgrow its capacity.
 #include "pt_trace.hpp"
 
+#include <atomic>
+
 namespace ptmi {
 
 namespace {
@@ -24,6 +26,36 @@ PT_DEV uint32_t *count_ptr(uint32_t *counts, int bounce, uint32_t q)
     return counts + ((size_t)bounce * kWfSubQueues + q) * kWfCountStride;
 }
 
+// The batch covers the pixel rectangle [x0, x0 + rect_w) x [y0, y0 + rect_h) (the whole frame for a
+// render, a part of it for the parity hook).  Paths are numbered over the rectangle's pixels in
+// row-major order; a path carries its frame-wide pixel index (the Philox counter).
+PT_DEV uint32_t rect_to_frame(const WavefrontParams &p, uint32_t local, uint32_t &x, uint32_t &y)
+{
+    const uint32_t ry = local / p.rect_w;
+    x = p.x0 + (local - ry * p.rect_w);
+    y = p.y0 + ry;
+    return y * p.cam.width + x;
+}
+
+PT_DEV uint32_t frame_to_rect(const WavefrontParams &p, uint32_t pix)
+{
+    if (p.rect_w == p.cam.width && p.x0 == 0u && p.y0 == 0u) return pix;   // wave-uniform
+    const uint32_t y = pix / p.cam.width, x = pix - y * p.cam.width;
+    return (y - p.y0) * p.rect_w + (x - p.x0);
+}
+
+// Index of a path within the batch: [iteration][pixel of the rectangle][sub-sample]
+PT_DEV size_t batch_path_index(const WavefrontParams &p, uint32_t n_pix, uint32_t pix, uint32_t it_sub)
+{
+    return (((size_t)((it_sub >> 2) - p.first_iteration) * n_pix + frame_to_rect(p, pix)) << 2) | (it_sub & 3);
+}
+
+// parity hook: primitive index the path's Intersect call of this bounce returned
+PT_DEV void record_hit(const WavefrontParams &p, uint32_t n_pix, uint32_t pix, uint32_t it_sub, int best)
+{
+    if (p.hit_ids) p.hit_ids[batch_path_index(p, n_pix, pix, it_sub) * (size_t)(p.max_bounces + 1) + p.bounce] = best;
+}
+
 template <bool TILED, bool BVH>
 __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontParams p)
 {
@@ -31,7 +63,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t q = blockIdx.x;                 // sub-queue
-    const uint32_t n_pix = p.cam.width * p.cam.height;
+    const uint32_t n_pix = p.rect_w * p.rect_h;
     const uint64_t n_paths = (uint64_t)p.n_iterations * n_pix * 4;
 
     // Number of 256-path chunks of this sub-queue.  Bounce 0 has no input queue: path i of the
@@ -62,9 +94,9 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
                 const uint32_t sub = (uint32_t)(i & 3);
                 const uint64_t ip = i >> 2;
                 const uint32_t it_off = (uint32_t)(ip / n_pix);
-                pix = (uint32_t)(ip - (uint64_t)it_off * n_pix);
+                uint32_t x, y;
+                pix = rect_to_frame(p, (uint32_t)(ip - (uint64_t)it_off * n_pix), x, y);
                 it_sub = ((p.first_iteration + it_off) << 2) | sub;
-                const uint32_t y = pix / p.cam.width, x = pix - y * p.cam.width;
                 d = camera_ray(p.cam, x, y, pix, it_sub >> 2, (int)sub, k0, k1);
             }
         } else {
@@ -87,13 +119,13 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
         if (active) {
             bool end = true;
             int b = p.bounce;
+            record_hit(p, n_pix, pix, it_sub, best);
             if (best >= 0) {
                 const float4 s = TILED ? p.scene.sph[best] : sc.sph[best];
                 end = shade_bounce(sc, s, best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
             }
             if (end) {
-                const size_t path = (((size_t)((it_sub >> 2) - p.first_iteration) * n_pix + pix) << 2) | (it_sub & 3);
-                float *pr = p.path_radiance + path * 3;
+                float *pr = p.path_radiance + batch_path_index(p, n_pix, pix, it_sub) * 3;
                 pr[0] = L.x; pr[1] = L.y; pr[2] = L.z;
             }
             cont = !end;
@@ -135,7 +167,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_bvh_kernel(const Wavefr
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
     const uint32_t q = blockIdx.x;
-    const uint32_t n_pix = p.cam.width * p.cam.height;
+    const uint32_t n_pix = p.rect_w * p.rect_h;
     const uint64_t n_paths = (uint64_t)p.n_iterations * n_pix * 4;
 
     // items of this sub-queue: item j is slot j of the input queue, or at bounce 0 path
@@ -184,9 +216,9 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_bvh_kernel(const Wavefr
                         const uint32_t sub = (uint32_t)(i & 3);
                         const uint64_t ip = i >> 2;
                         const uint32_t it_off = (uint32_t)(ip / n_pix);
-                        pix = (uint32_t)(ip - (uint64_t)it_off * n_pix);
+                        uint32_t x, y;
+                        pix = rect_to_frame(p, (uint32_t)(ip - (uint64_t)it_off * n_pix), x, y);
                         it_sub = ((p.first_iteration + it_off) << 2) | sub;
-                        const uint32_t y = pix / p.cam.width, x = pix - y * p.cam.width;
                         o = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
                         d = camera_ray(p.cam, x, y, pix, it_sub >> 2, (int)sub, k0, k1);
                         T = mk(1.f, 1.f, 1.f);
@@ -236,10 +268,10 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_bvh_kernel(const Wavefr
         if (fin) {
             bool end = true;
             int b = p.bounce;
+            record_hit(p, n_pix, pix, it_sub, best);
             if (best >= 0) end = shade_bounce(sc, p.scene.sph[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
             if (end) {
-                const size_t path = (((size_t)((it_sub >> 2) - p.first_iteration) * n_pix + pix) << 2) | (it_sub & 3);
-                float *pr = p.path_radiance + path * 3;
+                float *pr = p.path_radiance + batch_path_index(p, n_pix, pix, it_sub) * 3;
                 pr[0] = L.x; pr[1] = L.y; pr[2] = L.z;
             }
             cont = !end;
@@ -269,19 +301,25 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_bvh_kernel(const Wavefr
 // c = (((0+L0)+L1)+L2)+L3) * 1/4 and the running mean / sum of RenderKernel (pathtracer.cu:94-109).
 __global__ __launch_bounds__(kBlockThreads) void wf_resolve_kernel(const WavefrontParams p)
 {
-    const uint32_t n_pix = p.cam.width * p.cam.height;
-    const uint32_t pix = blockIdx.x * kBlockThreads + threadIdx.x;
-    if (pix < n_pix) {
-        float *px = p.buffer + (size_t)pix * 3;
-        V3 acc = p.overwrite ? mk(0.f, 0.f, 0.f) : mk(px[0], px[1], px[2]);
+    const uint32_t n_pix = p.rect_w * p.rect_h;
+    const uint32_t local = blockIdx.x * kBlockThreads + threadIdx.x;
+    if (local < n_pix) {
+        uint32_t x, y;
+        float *px = p.buffer ? p.buffer + (size_t)rect_to_frame(p, local, x, y) * 3 : nullptr;
+        V3 acc = (p.overwrite || !px) ? mk(0.f, 0.f, 0.f) : mk(px[0], px[1], px[2]);
+        V3 cpix = mk(0.f, 0.f, 0.f);
         for (uint32_t k = 0; k < p.n_iterations; ++k) {
-            const float *pr = p.path_radiance + (((size_t)k * n_pix + pix) << 2) * 3;
+            const float *pr = p.path_radiance + (((size_t)k * n_pix + local) << 2) * 3;
             V3 c = mk(0.f, 0.f, 0.f);
 #pragma unroll
             for (int s = 0; s < 4; ++s) c = c + mk(pr[s * 3], pr[s * 3 + 1], pr[s * 3 + 2]);
-            acc = accumulate_pixel(acc, c, p.first_iteration + k, p.accum_mode);
+            acc = accumulate_pixel(acc, c, p.first_iteration + k, p.accum_mode, &cpix);
         }
-        px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
+        if (px) { px[0] = acc.x; px[1] = acc.y; px[2] = acc.z; }
+        if (p.pixel_rgb) {   // parity hook: the colour of the batch's last iteration
+            float *pr = p.pixel_rgb + (size_t)local * 3;
+            pr[0] = cpix.x; pr[1] = cpix.y; pr[2] = cpix.z;
+        }
     }
     // Intersect calls of the batch = paths entering each bounce
     if (blockIdx.x == 0 && threadIdx.x < kWfSubQueues && p.ray_counter) {
@@ -310,6 +348,21 @@ hipError_t add_lane_stats_wavefront(unsigned long long out[64])
 #endif
 }
 
+// Compute units of the current device (looked up once per device; 256 if the query fails).
+static int current_device_cus()
+{
+    constexpr int kMaxDevices = 64;
+    static std::atomic<int> cached[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream_t stream)
 {
     // 64 sub-queues x up to 32 workgroups each (2048 workgroups = one resident set of the chip);
@@ -323,13 +376,7 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
         // One resident set of persistent workgroups: per CU as many as the traversal stacks in LDS
         // (2 KiB per tree level) and the kernel's registers (6 waves per SIMD) allow.  More would
         // run as a second round behind the first and wait for it.
-        static int n_cus = 0;
-        if (n_cus == 0) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0)
-                n_cus = 256;
-        }
+        const int n_cus = current_device_cus();
         uint32_t per_cu = (uint32_t)((160u * 1024u) / (lds ? lds : 1));
         if (per_cu > 6u) per_cu = 6u;
         if (per_cu < 1u) per_cu = 1u;
@@ -344,7 +391,7 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
 
 hipError_t launch_wavefront_resolve(const WavefrontParams &p, hipStream_t stream)
 {
-    const uint32_t n_pix = p.cam.width * p.cam.height;
+    const uint32_t n_pix = p.rect_w * p.rect_h;
     hipLaunchKernelGGL(wf_resolve_kernel, dim3((n_pix + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, stream, p);
     return hipGetLastError();
 }

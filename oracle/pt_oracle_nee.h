@@ -287,7 +287,7 @@ static v3 trace_nee(const scene_ctx *sc, v3 o, v3 d, uint32_t pixel, uint32_t it
             if (j > sc->n_lights - 1) j = sc->n_lights - 1;
             const ptor_light *light = &sc->lights[j];
             v3 wl;
-            float pdf_l;
+            float pdf_l = 0.f;   /* SampleLight leaves it unset for unknown light types (scene.h:169) */
             segment_t vt;
             v3 li = sample_light(sc, light, p, rl[0], rl[1], &wl, &pdf_l, &vt, 0);
             if (pdf_l > 0.f && !v3_is_black(li)) {

@@ -39,7 +39,7 @@ def O():
 
 def golden_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith(("camera", "nee_")))
+                  if not os.path.basename(p).startswith(("camera", "nee_", "t3_")))
 
 
 def load_golden(name):

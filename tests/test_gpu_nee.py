@@ -81,6 +81,28 @@ def test_point_light_and_several_lights(pt, O, torch_cuda):
     assert means[1] > 1.2 * means[0]
 
 
+def test_light_of_unknown_type_samples_to_black(pt, O, torch_cuda):
+    """SampleLight returns black for a type that is neither POINT_LIGHT nor AREA_LIGHT (scene.h:169);
+    such a light still emits when a path hits the sphere that carries it (Light::L does not look at
+    the type, light.h:43-45).  Its union bits are arbitrary and must never be read as a sphere index."""
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
+    lights = np.concatenate([lights, np.zeros(2, pt.LIGHT_DTYPE)])
+    lights["type"][1], lights["u_bits"][1], lights["intensity"][1] = 2, [0xdeadbeef, 0x7fffffff, 5], [40, 40, 40]
+    lights["type"][2], lights["u_bits"][2], lights["intensity"][2] = -7, [0xffffffff, 0, 0], [9, 9, 9]
+    sph = sph.copy()
+    sph["light_id"][6] = 1          # the mirror ball carries the type-2 light
+    cam = pt.Camera(eye, look, up, 48, 40, 0, 0, fov)
+    check_against_oracle(pt, O, torch_cuda, cam, mats, sph, lights, 6, 4)
+    # the plain integrator never samples lights: same scene, bit-exact too
+    ref, _, _, rays = O.oracle_render(cam.pod, mats, sph, lights, 4, 6, n_iterations=2)
+    tr = pt.Pathtracer(cam, 6, 4)
+    tr.Init(mats, sph, lights)
+    tr.ResetCounters()
+    assert render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes() == ref.tobytes()
+    assert tr.RayCount() == rays
+    tr.Release()
+
+
 def test_large_scene_through_the_bvh_and_the_tiled_scan(pt, O, torch_cuda):
     rng = np.random.default_rng(8)
     mats = materials(pt, [(0, 0.0), (1, 0.9), (2, 1.33), (0, 0.0)])

@@ -49,11 +49,17 @@ def render(torch, tr, first_iteration, n_iterations, batched=True, buf=None):
     return buf
 
 
+# The kernels a render goes through: what ships by default (PT_VARIANT_AUTO: the work-stealing
+# megakernel, or the per-bounce wavefront launches for BVH scenes) and the plain megakernel.
+SHIPPED_VARIANTS = [-1, 0]   # pt.VARIANT_AUTO, pt.VARIANT_REGENERATION
+
+
+@pytest.mark.parametrize("variant", SHIPPED_VARIANTS)
 @pytest.mark.parametrize("name", golden_names())
-def test_image_matches_golden_bit_exact(pt, torch_cuda, name):
+def test_image_matches_golden_bit_exact(pt, torch_cuda, name, variant):
     """Frame buffer after the fixture's iteration range == the reference host build's."""
     g = load_golden(name)
-    tr = make_tracer(pt, g)
+    tr = make_tracer(pt, g, variant)
     tr.ResetCounters()
     buf = render(torch_cuda, tr, int(g["first_iteration"]), int(g["n_iterations"]))
     img = buf.cpu().numpy().reshape(g["image"].shape)
@@ -63,10 +69,15 @@ def test_image_matches_golden_bit_exact(pt, torch_cuda, name):
     tr.Release()
 
 
+# + 3: whole pixel-iterations change hands even in a one-iteration launch (the default there: single paths)
+@pytest.mark.parametrize("variant", SHIPPED_VARIANTS + [500 + 3, 100])
 @pytest.mark.parametrize("name", golden_names())
-def test_hit_ids_and_path_radiance_match_golden(pt, torch_cuda, name):
+def test_hit_ids_and_path_radiance_match_golden(pt, torch_cuda, name, variant):
+    """pt_debug_trace runs the rectangle through the kernels a render of the instance would use
+    (work stealing included: a stolen path is recorded by the lane that traced it), so the hit-index
+    sequences and per-path radiances of the reference's host build are compared with what ships."""
     g = load_golden(name)
-    tr = make_tracer(pt, g)
+    tr = make_tracer(pt, g, variant)
     w, h = int(g["width"]), int(g["height"])
     hits_all, rad_all, rays = [], [], 0
     for it in range(int(g["first_iteration"]), int(g["first_iteration"]) + int(g["n_iterations"])):
@@ -180,19 +191,21 @@ def test_empty_and_degenerate_scenes(pt, O, torch_cuda):
     assert ref_rays > 0
 
 
-def test_debug_trace_sub_rectangle(pt, torch_cuda):
+@pytest.mark.parametrize("variant", SHIPPED_VARIANTS + [100])
+def test_debug_trace_sub_rectangle(pt, torch_cuda, variant):
     g = load_golden("demo_64x64_d4_it1")
-    tr = make_tracer(pt, g)
+    tr = make_tracer(pt, g, variant)
     hits, rad, _, _ = tr.DebugTrace(5, 9, 41, 30, 1)
     assert np.array_equal(hits, g["hit_ids"][0, 9:30, 5:41].astype(np.int32))
     assert rad.tobytes() == np.ascontiguousarray(g["path_radiance"][0, 9:30, 5:41]).tobytes()
     tr.Release()
 
 
-def test_run_per_iteration_equals_batched_and_host_buffer(pt, torch_cuda):
+@pytest.mark.parametrize("variant", SHIPPED_VARIANTS)
+def test_run_per_iteration_equals_batched_and_host_buffer(pt, torch_cuda, variant):
     """n x pt_run == pt_run_n(n) == pt_run on a host buffer (Pathtracer::Run semantics)."""
     g = load_golden("demo_64x48_d8_it1-4")
-    tr = make_tracer(pt, g)
+    tr = make_tracer(pt, g, variant)
     a = render(torch_cuda, tr, 1, 4, batched=True).cpu().numpy()
     b = render(torch_cuda, tr, 1, 4, batched=False).cpu().numpy()
     assert a.tobytes() == b.tobytes() == g["image"].tobytes()
@@ -498,6 +511,76 @@ def test_full_size_properties_1080p(pt, O, torch_cuda):
     tr.Release()
 
 
+def _oracle_bands(O, cam, mats, sph, lights, depth, n, bands):
+    return {y0: O.oracle_render(cam.pod, mats, sph, lights, 1, depth, n_iterations=n,
+                                rect=(0, y0, cam.Width(), y0 + rows), n_threads=8)[0][y0:y0 + rows]
+            for (y0, rows) in bands}
+
+
+def test_config2_as_benchmarked_1080p_64_iterations(pt, O, torch_cuda):
+    """The headline configuration exactly as bench.py times it: demo scene, 1920x1080, depth 8,
+    64 iterations in ONE pt_run_n with the default variant -- 8160 tiles x 3 iteration ranges, about
+    24 000 workgroups for some 1 500 resident slots, so the ticket order, the per-tile hand-over of
+    the frame buffer between workgroups (possibly on different XCDs) and the scratch-block pool all
+    work under real oversubscription.  Against the plain megakernel (image bytes, ray count), a
+    forced 4-range launch, and oracle row bands at the top, middle and bottom of the frame."""
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
+    cam = pt.Camera(eye, look, up, 1920, 1080, 0, 0, fov)
+    imgs, rays = {}, {}
+    for variant in (pt.VARIANT_AUTO, pt.VARIANT_REGENERATION, pt.VARIANT_STEALING + 13):
+        tr = pt.Pathtracer(cam, 8, 1)
+        tr.Init(mats, sph, lights)
+        tr.SetKernelVariant(variant)
+        tr.ResetCounters()
+        imgs[variant] = render(torch_cuda, tr, 1, 64).cpu().numpy().reshape(1080, 1920, 3)
+        rays[variant] = tr.RayCount()
+        tr.Release()
+    ref = imgs[pt.VARIANT_REGENERATION]
+    for variant in imgs:
+        assert imgs[variant].tobytes() == ref.tobytes(), variant
+        assert rays[variant] == rays[pt.VARIANT_REGENERATION]
+    for y0, band in _oracle_bands(O, cam, mats, sph, lights, 8, 64, [(0, 2), (539, 2), (1078, 2)]).items():
+        assert imgs[pt.VARIANT_AUTO][y0:y0 + 2].tobytes() == band.tobytes(), y0
+
+
+def test_config5_as_benchmarked_1080p_depth16_32_iterations(pt, O, torch_cuda):
+    """The mixed-material configuration as bench.py --workload mixed16 times it (71 spheres, depth
+    16 with Russian roulette, 32 iterations, default variant) against the plain megakernel and
+    oracle row bands."""
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_MIXED)
+    cam = pt.Camera(eye, look, up, 1920, 1080, 0, 0, fov)
+    imgs, rays = {}, {}
+    for variant in (pt.VARIANT_AUTO, pt.VARIANT_REGENERATION):
+        tr = pt.Pathtracer(cam, 16, 1)
+        tr.Init(mats, sph, lights)
+        tr.SetKernelVariant(variant)
+        tr.ResetCounters()
+        imgs[variant] = render(torch_cuda, tr, 1, 32).cpu().numpy().reshape(1080, 1920, 3)
+        rays[variant] = tr.RayCount()
+        tr.Release()
+    assert imgs[pt.VARIANT_AUTO].tobytes() == imgs[pt.VARIANT_REGENERATION].tobytes()
+    assert rays[pt.VARIANT_AUTO] == rays[pt.VARIANT_REGENERATION]
+    for y0, band in _oracle_bands(O, cam, mats, sph, lights, 16, 32, [(300, 1), (700, 2)]).items():
+        assert imgs[pt.VARIANT_AUTO][y0:y0 + band.shape[0]].tobytes() == band.tobytes(), y0
+
+
+def test_benchmark_sampling_matches_injected_reference_image(pt, torch_cuda):
+    """256x256, depth 8, 64 iterations (the benchmark's depth and sampling): the default kernels'
+    image is the reference host build's, bit for bit (fixture: oracle/gen_golden.py t3)."""
+    g = load_golden("t3_libm_demo_256x256_d8_it1-64")
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
+    cam = pt.Camera(eye, look, up, 256, 256, 0, 0, fov)
+    for variant in SHIPPED_VARIANTS + [pt.VARIANT_WAVEFRONT]:
+        tr = pt.Pathtracer(cam, 8, 1)
+        tr.Init(mats, sph, lights)
+        tr.SetKernelVariant(variant)
+        tr.ResetCounters()
+        img = render(torch_cuda, tr, 1, 64).cpu().numpy()
+        assert tr.RayCount() == int(g["ray_count_injected"]), variant
+        assert sha(img) == str(g["image_injected_sha256"]), variant
+        tr.Release()
+
+
 def test_config3_size_4k_tile_split_over_8_ranks(pt, torch_cuda):
     """The 4K benchmark configuration's frame (3840x2160) split into 16-row bands over 8 ranks: the sum of
     the ranks' buffers is the 1-rank image bit for bit, and the ray counts add up."""
@@ -524,8 +607,10 @@ def test_config3_size_4k_tile_split_over_8_ranks(pt, torch_cuda):
 
 
 def test_config4_size_synth10k_1080p_rows_against_oracle(pt, O, torch_cuda):
-    """The 10 007-sphere benchmark configuration at 1080p: one iteration through the LDS-tiled scan;
-    four rows spread over the frame are compared with the oracle bit for bit."""
+    """The 10 007-sphere benchmark configuration at 1080p, one iteration with the default variant
+    (sphere BVH, per-bounce wavefront launches with dynamic ray fetch) against an explicit
+    PT_VARIANT_WAVEFRONT instance; four rows spread over the frame are compared with the oracle
+    (a linear scan) bit for bit."""
     mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_SYNTH10K, 1)
     cam = pt.Camera(eye, look, up, 1920, 1080, 0, 0, fov)
     tr = pt.Pathtracer(cam, 8, 1)
