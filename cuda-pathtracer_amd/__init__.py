@@ -54,6 +54,7 @@ ABI = [
     ("pt_last_error", ctypes.c_char_p, [_vp]),
     ("pt_run", _i32, [_vp, _vp, _i32]),
     ("pt_run_n", _i32, [_vp, _vp, _u32, _i32]),
+    ("pt_run_n_noalloc", _i32, [_vp, _vp, _u32, _i32]),
     ("pt_reset", _i32, [_vp]),
     ("pt_iteration", _u32, [_vp]),
     ("pt_set_camera", _i32, [_vp, _vp]),
@@ -281,6 +282,10 @@ class Pathtracer:
 
     def RunN(self, dev_buffer, n_iterations: int, sync: bool = True) -> None:
         self._check(self._lib.pt_run_n(self._h, _vp(_devptr(dev_buffer, self)), n_iterations, int(sync)))
+
+    def RunNNoAlloc(self, dev_buffer, n_iterations: int, sync: bool = True) -> None:
+        """RunN through the entry point that allocates no device memory (static scratch)."""
+        self._check(self._lib.pt_run_n_noalloc(self._h, _vp(_devptr(dev_buffer, self)), n_iterations, int(sync)))
 
     def SetCamera(self, camera) -> None:
         pod = camera.pod if isinstance(camera, Camera) else np.ascontiguousarray(camera, CAMERA_DTYPE)

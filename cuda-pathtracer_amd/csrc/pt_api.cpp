@@ -44,6 +44,7 @@ struct pt_context {
     unsigned long long *d_ray_counter;
     void *d_steal;             // scratch pool of the work-stealing megakernel + its occupancy bits, allocated on first use
     bool steal_alloc_failed;   // the pool could not be allocated: render without stealing, do not try again
+    StealScratch fixed_scratch; // this device's copy of the statically allocated scratch (pt_run_n_noalloc)
     bool steal;                // work stealing inside the wave where the kernel supports it
     uint64_t memory_limit;     // pt_set_memory_limit: bytes of device memory the library may allocate; 0 = no limit
     uint32_t *d_tickets;       // chunked launches: start-order counter + one progress word per tile
@@ -163,6 +164,7 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->d_ray_counter = nullptr;
     h->d_steal = nullptr;
     h->steal_alloc_failed = false;
+    memset(&h->fixed_scratch, 0, sizeof h->fixed_scratch);
     h->steal = true;           // PT_VARIANT_AUTO
     h->memory_limit = 0;
     h->d_tickets = nullptr;
@@ -186,6 +188,12 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
         hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess) {
         pt_destroy(h);
         return fail(nullptr, PT_ERR_DEVICE, "pt_create: device allocation failed");
+    }
+    // address of this device's copy of the statically allocated scratch, looked up once per device
+    if (hipError_t se = static_steal_scratch(dev, &h->fixed_scratch); se != hipSuccess) {
+        pt_destroy(h);
+        return fail(nullptr, PT_ERR_DEVICE, "pt_create: hipGetSymbolAddress of the static scratch failed: %s",
+                    hipGetErrorString(se));
     }
     *out = h;
     return PT_OK;
@@ -852,6 +860,28 @@ int pt_run_n(pt_handle h, float *device_buffer, uint32_t n_iterations, int sync)
     if (!h) return PT_ERR_INVALID;
     DeviceGuard on_device(h->device);
     int rc = enqueue(h, device_buffer, n_iterations);
+    if (rc != PT_OK) return rc;
+    if (sync) PT_HIP(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
+int pt_run_n_noalloc(pt_handle h, float *device_buffer, uint32_t n_iterations, int sync)
+{
+    if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
+    if (!h->scene_ready) return fail(h, PT_ERR_STATE, "render before pt_init_scene");
+    if (!device_buffer) return fail(h, PT_ERR_INVALID, "render: buffer is NULL");
+    if (h->wavefront)
+        return fail(h, PT_ERR_STATE, "pt_run_n_noalloc: the wavefront variant needs queues that grow with the frame; "
+                                     "select PT_VARIANT_AUTO or a megakernel variant");
+    const uint64_t tiles = (uint64_t)div_up(h->camera.width, 16) * div_up(h->camera.height, 16);
+    if (tiles + 1 > h->fixed_scratch.ticket_words)
+        return fail(h, PT_ERR_INVALID, "pt_run_n_noalloc: %ux%u is %llu tiles of 16x16 pixels, the static scratch "
+                    "holds tickets for %u", h->camera.width, h->camera.height, (unsigned long long)tiles,
+                    h->fixed_scratch.ticket_words - 1);
+    if (n_iterations == 0) return PT_OK;
+    if (h->iteration > 0xffffffffu - n_iterations) return fail(h, PT_ERR_INVALID, "iteration counter overflow");
+    const int rc = enqueue_megakernel(h, device_buffer, n_iterations, &h->fixed_scratch);
     if (rc != PT_OK) return rc;
     if (sync) PT_HIP(h, hipStreamSynchronize(h->stream));
     return PT_OK;

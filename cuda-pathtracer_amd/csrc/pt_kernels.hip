@@ -18,6 +18,8 @@
 // scenes are staged once per workgroup; larger ones stream through a 1024-sphere LDS tile.
 #include "pt_nee.hpp"
 
+#include <mutex>
+
 namespace ptmi {
 
 namespace {
@@ -626,6 +628,41 @@ hipError_t read_lane_stats(unsigned long long out[64])
     for (int i = 0; i < 64; ++i) out[i] = 0;
     return hipSuccess;
 #endif
+}
+
+// ---- statically allocated scratch of the entry point that allocates nothing ------------------------------
+// Scratch of the work-stealing megakernel for pt_run_n_noalloc: the pool of scratch blocks, its
+// occupancy bits, and the tickets of chunked launches (start-order counter + one word per
+// 16x16-pixel tile, so frames of up to kStaticTicketWords - 1 tiles), 48.3 MiB in all.  Every GPU
+// the library runs on holds its own copy at its own address until the process ends.  In host code
+// the array's name is only a handle for hipGetSymbolAddress; kernels get the looked-up address as
+// an argument.
+static __device__ __attribute__((used)) __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+hipError_t static_steal_scratch(int device, StealScratch *out)
+{
+    constexpr int kMaxDevices = 64;
+    static std::mutex mutex;
+    static void *address[kMaxDevices];   // per device: that device's copy of `scratch`
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mutex);
+    if (!address[device]) {
+        int current = -1;
+        hipError_t e = hipGetDevice(&current);
+        if (e != hipSuccess) return e;
+        if (current != device) return hipErrorInvalidDevice;   // the symbol resolves on the current device
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        address[device] = ptr;
+    }
+    unsigned char *base = static_cast<unsigned char *>(address[device]);
+    out->pool = reinterpret_cast<float *>(base);
+    out->mask = reinterpret_cast<unsigned long long *>(base + kStealPoolBytes);
+    out->tickets = reinterpret_cast<uint32_t *>(base + kStealPoolBytes + kStealMaskBytes);
+    out->ticket_words = kStaticTicketWords;
+    return hipSuccess;
 }
 
 size_t scene_lds_bytes(const SceneParams &s, bool tiled)

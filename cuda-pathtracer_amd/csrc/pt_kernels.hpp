@@ -52,6 +52,14 @@ struct StealScratch {
     uint32_t ticket_words;
 };
 
+// The statically allocated scratch (a file-scope __device__ array in pt_kernels.hip): pool, occupancy
+// bits and kStaticTicketWords ticket words, contiguous in this order.
+constexpr uint32_t kStaticTicketWords = 1u << 16;
+constexpr size_t kStaticScratchBytes = kStealPoolBytes + kStealMaskBytes + (size_t)kStaticTicketWords * sizeof(uint32_t);
+// Address of the CURRENT device's copy (`device` must be the current device), looked up with
+// hipGetSymbolAddress once per device and kept.
+hipError_t static_steal_scratch(int device, StealScratch *out);
+
 // Sphere BVH in device memory (layout: pt_bvh.hpp); n_nodes == 0 when there is none.
 struct BvhParams {
     const float4 *nodes;      // four float4 per inner node, node 0 is the root

@@ -118,6 +118,18 @@ int pt_run(pt_handle h, float *buffer, int buffer_is_device);
  * after enqueueing on the stream. */
 int pt_run_n(pt_handle h, float *device_buffer, uint32_t n_iterations, int sync);
 
+/* pt_run_n for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
+ * results as pt_run_n, bit for bit; the call itself performs no hipMalloc / hipFree: the scratch
+ * of the work-stealing megakernel (blocks for results that change hands between lanes, tickets
+ * of the iteration ranges) is a statically allocated 48.3 MiB array that every GPU the library
+ * runs on holds until the process ends.  Limits: frames of at most 65 535 tiles of 16x16 pixels
+ * (e.g. 4096x4080; PT_ERR_INVALID beyond); megakernel variants only -- PT_VARIANT_AUTO renders
+ * BVH scenes through the BVH megakernel here, PT_VARIANT_WAVEFRONT is refused with PT_ERR_STATE
+ * (its queues grow with the frame).  All calls on one GPU share that GPU's array: calls that
+ * overlap in time on one GPU (different handles or streams) race; calls on one stream do not. */
+int pt_run_n_noalloc(pt_handle h, float *device_buffer, uint32_t n_iterations, int sync);
+
 /* Pathtracer::Reset, pathtracer.cu:245-247: iteration = 0. */
 int pt_reset(pt_handle h);
 
