@@ -9,11 +9,21 @@ The metric is path-bounces per second: the number of Intersect calls (primary ra
 scene.h:71-94), counted exactly by the kernel, divided by wall time with the frame buffer
 resident in HBM.
 
-N > 1 (one process per GPU, launched by torch.distributed.run): sample-range split -- every
-rank renders the same frame for its own block of iterations into a SUM buffer (per-GPU work
-fixed: weak scaling) and one RCCL reduce of the accumulation buffers ends the step.  Steps
-alternate between two buffers, so the reduce of step k (on RCCL's stream) runs while step k+1
-renders; the timed region ends when every reduce has completed.
+N > 1: one process per GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE set) this process
+is one rank; typed as plain `python bench.py --gpus N` it starts the N ranks itself -- as a child
+`python -m torch.distributed.run ... bench.py <same arguments>`, before this process has made any
+GPU call -- and relays rank 0's JSON line.
+  --split sample (default): every rank renders the same frame for its own block of iterations
+      into a SUM buffer and one RCCL reduce(sum) of the accumulation buffers ends the step;
+  --split tile: every rank renders its 16-row bands (band b -> rank b % N) for ALL world x
+      iterations iterations, other pixels stay zero, the same reduce(sum) assembles the image,
+      bit-identical to a one-GPU render.
+Either way per-GPU work is fixed as N grows (weak scaling: the job is N x iterations iterations
+of the frame).  Steps alternate between two buffers, so the reduce of step k (on RCCL's stream)
+runs while step k+1 renders; the timed region ends when every reduce has completed.  The N > 1
+line also carries `rccl_ranks_seen` (an all-reduce of ones) and `image_rmse_vs_single_rank`
+(rank 0 re-renders a few row bands of the whole job alone and compares them with the reduced
+frame).  --workload demo4k is the 8-GPU configuration's frame (3840x2160, 128 iterations per GPU).
 
 Adds to the JSON line:
   roofline      FP32 vector-ALU roofline of the render kernel: algorithmic flops per launch
@@ -67,13 +77,35 @@ def flops_per_ray_bvh(workload: str):
     return 121 + 17 * v["always_tested_spheres"] + 44 * v["inner_per_ray"] + 4 * 17 * v["leaves_per_ray"]
 
 
+def host_description():
+    """The host the CPU baseline runs on: CPU model, the cores this process may use and the cores
+    it does use.  On a shared GPU box the affinity mask shows the whole machine while the box's
+    share per GPU is what OMP_NUM_THREADS says (16); the baseline uses every core of that share."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    affinity = len(os.sched_getaffinity(0))
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    share = int(share) if share.isdigit() and int(share) > 0 else None
+    used = max(1, min(affinity, share) if share else affinity)
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "cores_available_affinity": affinity,
+            "cores_share_of_this_gpu": share, "cores_used": used}
+
+
 def cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render=None):
     """Time the CPU oracle on a bounded sample of the same workload (about 10-30 s of CPU work).
     gpu_render(n_iterations) -> numpy image: when given, the oracle's rows are also compared with
     the GPU's image of the same iterations (image RMSE / max abs difference; expected 0)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
-    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    host = host_description()
+    threads = host["cores_used"]
     w, h = wl["width"], wl["height"]
     # ~15 s of CPU work: the oracle does about 5.4e6 Intersect calls/s/thread on 9 spheres
     # and scales with the number of sphere tests per call
@@ -91,7 +123,8 @@ def cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render=None):
     dt = time.perf_counter() - t0
     out = {"value": rays / dt, "unit": "path-bounces/s", "cores": threads, "kind": "port",
            "sample": f"{wl['label']}: rows {y0}..{y0 + rows} x {iters} iteration(s), {rays} Intersect calls "
-                     f"in {dt:.2f} s on {threads} threads (oracle/pt_oracle.c)"}
+                     f"in {dt:.2f} s on {threads} threads (oracle/pt_oracle.c)",
+           "host": host}
     if gpu_render is not None:
         import numpy as np
         diff = gpu_render(iters)[y0:y0 + rows].astype(np.float64) - cpu_img[y0:y0 + rows]
@@ -114,6 +147,43 @@ def cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render=None):
     return out
 
 
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as a child
+    `python -m torch.distributed.run` of this same script.  This process has not touched the GPU
+    (torch is not even imported here); it waits for the child, relays rank 0's JSON line on
+    stdout and returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in proc.stdout.splitlines():
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def pmc_summary(tag_path: str):
+    """Issue-slot utilisation and active-lane fraction of the render kernel from the committed PMC
+    passes of this same command (profiles/pmc_*.json, written by tools/summarize_prof.py)."""
+    if not os.path.exists(tag_path):
+        return {}
+    with open(tag_path) as f:
+        v = json.load(f)
+    return {k: v[k] for k in ("hbm_bytes_per_step", "valu_issue_util", "active_lane_frac", "wait_frac") if k in v}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,7 +200,13 @@ def main():
                     help="path: the reference's Trace (the headline metric); nee: opt-in direct-light sampling "
                          "with MIS (bounces then include the shadow rays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split", default="sample", choices=["sample", "tile"],
+                    help="N > 1: sample-range split (each rank its own iterations, SUM buffers) or tile split "
+                         "(each rank its own 16-row bands of all iterations); one RCCL reduce(sum) either way")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     # Libraries print banners on stdout (RCCL its version block, gloo its connection report):
     # everything but the result line goes to stderr.
@@ -179,15 +255,22 @@ def main():
     # linear-scan scenes render with the work-stealing megakernel, BVH scenes with the wavefront variant
     eff_variant = args.variant if args.variant >= 0 else ((100 if bvh else 500) if args.integrator == "path" else 0)
     tr.SetStream(torch.cuda.current_stream().cuda_stream)
-    if grouped:
+    tile_split = grouped and args.split == "tile"
+    if grouped and not tile_split:
         tr.SetAccumMode(pt.ACCUM_SUM)
+    if tile_split:
+        tr.SetRowBands(16, rank, world)
     # N > 1: two accumulation buffers, so that the reduce of one step (on RCCL's stream) overlaps
     # with the render of the next step into the other buffer
     n_px = wl["width"] * wl["height"] * 3
     bufs = [torch.zeros(n_px, dtype=torch.float32, device=device) for _ in range(2 if grouped else 1)]
     buf = bufs[0]
     pending = [None] * len(bufs)
-    first, n_it = sharding.sample_range(rank, world, wl["iterations"])
+    if tile_split:   # every rank renders all world x iterations iterations of its own bands
+        first, n_it = 1, wl["iterations"] * world
+    else:
+        first, n_it = sharding.sample_range(rank, world, wl["iterations"])
+    total_iterations = wl["iterations"] * world
     step_no = [0]
 
     def finish(slot):
@@ -195,14 +278,16 @@ def main():
         root has turned the sum into the mean."""
         if pending[slot] is not None:
             pending[slot].wait()
-            if rank == 0:
-                bufs[slot].mul_(1.0 / float(world * n_it))
+            if rank == 0 and not tile_split:
+                bufs[slot].mul_(1.0 / float(total_iterations))
             pending[slot] = None
 
     def step():
         slot = step_no[0] % len(bufs)
         step_no[0] += 1
         finish(slot)
+        if tile_split:
+            bufs[slot].zero_()      # foreign bands must be zero (on the root they hold the last sum)
         tr.Reset()
         tr.SetIteration(first - 1)
         tr.RunN(bufs[slot], n_it, sync=False)
@@ -213,8 +298,8 @@ def main():
                 host = bufs[slot].cpu()
                 sharding.reduce_to_root(host, dist, 0, single_rank_too=True)
                 bufs[slot].copy_(host)
-                if rank == 0:
-                    bufs[slot].mul_(1.0 / float(world * n_it))
+                if rank == 0 and not tile_split:
+                    bufs[slot].mul_(1.0 / float(total_iterations))
 
     def fence():
         for slot in range(len(bufs)):
@@ -249,19 +334,50 @@ def main():
     dt_max = all_reduce_scalar(dt, dist.ReduceOp.MAX)
     rays_total = all_reduce_scalar(float(rays_local), dist.ReduceOp.SUM)
 
+    # N > 1 self-check: how many ranks the collective really spans, and the reduced frame of the
+    # last step against rank 0 rendering a few row bands of the WHOLE job (all world x iterations
+    # iterations) alone.  Outside the timed region.
+    multi = None
+    if grouped:
+        grouped_launch_ms = tr.LastKernelMs()     # the last timed launch (before the check render below)
+        ranks_seen = int(round(all_reduce_scalar(1.0, dist.ReduceOp.SUM)))
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: cuda:{dev_index} {torch.cuda.get_device_name(dev_index)}")
+        multi = {"rccl_ranks_seen": ranks_seen, "backend": backend, "split": args.split, "ranks": names}
+        if rank == 0:
+            last = bufs[(step_no[0] - 1) % len(bufs)].clone()
+            solo = torch.zeros_like(last)
+            check_world = 68      # bands 0, 68, ...: rows 0-15 and 1088-1103 ... of the frame
+            while check_world > 1 and (wl["height"] + 15) // 16 <= check_world:
+                check_world //= 2
+            tr.SetAccumMode(pt.ACCUM_RUNNING_MEAN)
+            tr.SetRowBands(16, 0, check_world)
+            tr.Reset()
+            tr.RunN(solo, total_iterations, sync=True)
+            rows = [r for (y0, y1) in sharding.owned_bands(wl["height"], 16, 0, check_world) for r in range(y0, y1)]
+            a = last.view(wl["height"], wl["width"], 3)[rows].double()
+            b = solo.view(wl["height"], wl["width"], 3)[rows].double()
+            multi["image_rmse_vs_single_rank"] = float(((a - b) ** 2).mean().sqrt())
+            multi["image_max_abs_vs_single_rank"] = float((a - b).abs().max())
+            multi["image_check"] = (f"{len(rows)} rows x {total_iterations} iterations re-rendered by rank 0 alone "
+                                    f"(running mean); mean radiance {float(b.mean()):.4f}; "
+                                    + ("tile split: expected 0" if tile_split else
+                                       "sample split sums in another order: expected ~1e-7 relative"))
+            # restore this rank's configuration
+            tr.SetAccumMode(pt.ACCUM_RUNNING_MEAN if tile_split else pt.ACCUM_SUM)
+            tr.SetRowBands(16, rank, world) if tile_split else tr.SetRowBands(16, 0, 1)
+
     # Average launch duration of the render kernel: at N=1 the timed region is nothing but the
     # K launches, so the event pair around it gives it directly; with a reduce in the step the
     # library's own event pair around the last launch is used instead.
-    launch_ms = region_ms / args.steps if not grouped else tr.LastKernelMs()
+    launch_ms = region_ms / args.steps if not grouped else grouped_launch_ms
     rays_per_launch = rays_local / max(1, args.steps)
     fpr = flops_per_ray_bvh(args.workload) if bvh else flops_per_ray(len(sph))
     # HBM bytes per step from the committed PMC passes of this same command (rocprofv3 cannot be
     # run from inside the benchmark): profiles/pmc_traffic_<workload>_v<variant>.json
-    traffic = None
     tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}{'_bvh' if bvh else ''}_v{eff_variant}.json")
-    if os.path.exists(tpath) and args.integrator == "path":
-        with open(tpath) as f:
-            traffic = json.load(f).get("hbm_bytes_per_step")
+    pmc = pmc_summary(tpath) if args.integrator == "path" else {}
+    traffic = pmc.get("hbm_bytes_per_step")
     achieved = rays_per_launch * fpr / (launch_ms * 1e-3) / 1e12 if fpr else None
 
     if rank == 0:
@@ -276,10 +392,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl["label"], "paths_per_step_per_gpu": wl["width"] * wl["height"] * 4 * n_it,
+            "config": {"workload": wl["label"], "paths_per_step_per_gpu": wl["width"] * wl["height"] * 4 * n_it // (world if tile_split else 1),
                        "bounces_per_step_per_gpu": rays_per_launch, "spheres": int(len(sph)),
                        "parallelism": "single" if world == 1 else
-                                      f"sample-range split x{world} + RCCL reduce(sum) overlapped with the next render",
+                                      f"{'tile (16-row bands)' if tile_split else 'sample-range'} split x{world} + "
+                                      f"RCCL reduce(sum) overlapped with the next render",
                        "kernel_variant": eff_variant,
                        "nearest_hit": "sphere BVH" if bvh else "linear scan", "integrator": args.integrator},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
@@ -288,12 +405,19 @@ def main():
                          # contract (bit-exact parity), so half of it is reachable with plain ops
                          "frac_of_unfused_peak": achieved / (PEAK_FP32_VALU_TFLOPS / 2) if achieved else None,
                          "traffic": traffic,
+                         # from the committed PMC passes of this command (profiles/): share of the SIMDs'
+                         # VALU issue slots in use, lanes active per VALU instruction, wave time in s_waitcnt
+                         "valu_issue_util": pmc.get("valu_issue_util"),
+                         "active_lane_frac": pmc.get("active_lane_frac"),
+                         "wait_frac": pmc.get("wait_frac"),
                          "kernel": ("render_kernel" if eff_variant < 100 else
                                     "render_steal_kernel" if eff_variant >= 500 else
                                     "wf_step_* (all launches of a step)"),
                          "launch_ms": launch_ms,
                          "flops_per_bounce": fpr, "bounces_per_launch": rays_per_launch},
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         if not grouped and not args.no_cpu_baseline and args.integrator == "path":
             def gpu_render(n):
                 tr.Reset()

@@ -91,8 +91,19 @@ def main():
         # both are reported in KiB
         import json
         with open(sys.argv[2], "w") as f:
+            extra = {}
+            # share of the VALU issue slots in use: a SIMD issues one fp32 wave64 instruction per 2
+            # cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs, the chip has 1024 SIMDs
+            if g("SQ_INSTS_VALU") and g("GRBM_GUI_ACTIVE"):
+                extra["valu_issue_util"] = g("SQ_INSTS_VALU") / (1024 * (g("GRBM_GUI_ACTIVE") / 8) / 2)
+            if g("SQ_ACTIVE_INST_VALU") and g("SQ_THREAD_CYCLES_VALU"):
+                extra["active_lane_frac"] = g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_ACTIVE_INST_VALU"))
+            if g("SQ_WAIT_ANY") and g("SQ_WAVE_CYCLES"):
+                extra["wait_frac"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
+            if g("SQ_INSTS_VALU"):
+                extra["valu_wave_instructions_per_step"] = g("SQ_INSTS_VALU")
             json.dump({"tag": tag, "fetch_bytes": g("FETCH_SIZE") * 1024 * 2, "write_bytes": g("WRITE_SIZE", 0.0) * 1024,
-                       "hbm_bytes_per_step": g("FETCH_SIZE") * 1024 * 2 + g("WRITE_SIZE", 0.0) * 1024,
+                       "hbm_bytes_per_step": g("FETCH_SIZE") * 1024 * 2 + g("WRITE_SIZE", 0.0) * 1024, **extra,
                        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per bench step; "
                                "FETCH_SIZE x2 (gfx950 correction for wide coalesced reads)"}, f, indent=1)
     if g("FETCH_SIZE") is not None:
