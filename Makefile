@@ -42,9 +42,9 @@ examples: examples/pt_headless tools/pt_bench
 tools/pt_bench: tools/pt_bench.cpp $(PKG)/libptmi.so
 	$(HIPCC) -O2 -std=c++17 -Iinclude -o $@ tools/pt_bench.cpp -L$(PKG) -lptmi -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
-examples/pt_headless: examples/main.cpp $(PKG)/host/pathtracer.hpp $(PKG)/libptmi.so
+examples/pt_headless: examples/main.cpp $(PKG)/host/pathtracer.hpp $(PKG)/host/multi_gpu.hpp $(PKG)/host/scene_file.hpp $(PKG)/libptmi.so
 	$(HIPCC) -O2 -std=c++17 -ffp-contract=off -Iinclude -I$(PKG)/host -o $@ examples/main.cpp \
-	    -L$(PKG) -lptmi -Wl,-rpath,'$$ORIGIN/../$(PKG)'
+	    -L$(PKG) -lptmi -L/opt/rocm/lib -lrccl -lpthread -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
 clean:
 	rm -f $(PKG)/libptmi.so examples/pt_headless

@@ -170,14 +170,20 @@ public:
     void Reset() { check(pt_reset(handle_)); }
     uint32_t GetIteration() const { return pt_iteration(handle_); }
     // Not in the reference: n Run() calls in one launch, checkpoint files, nearest-hit search mode.
-    void RunN(float *devBuffer, uint32_t n)
+    void RunN(float *devBuffer, uint32_t n, bool sync = true)
     {
         check(pt_set_camera(handle_, &camera_->Pod()));
-        check(pt_run_n(handle_, devBuffer, n, 1));
+        check(pt_run_n(handle_, devBuffer, n, sync ? 1 : 0));
     }
     void SaveCheckpoint(const float *devBuffer, const std::string &path) { check(pt_save_checkpoint(handle_, devBuffer, path.c_str())); }
     void LoadCheckpoint(float *devBuffer, const std::string &path) { check(pt_load_checkpoint(handle_, devBuffer, path.c_str())); }
     void SetAccel(int mode) { check(pt_set_accel(handle_, mode)); }
+    // Sharding plumbing (pt_set_stream, pt_set_accum_mode, pt_set_iteration, pt_set_row_bands, pt_ray_count).
+    void SetStream(void *hipStream) { check(pt_set_stream(handle_, hipStream)); }
+    void SetAccumMode(int mode) { check(pt_set_accum_mode(handle_, mode)); }
+    void SetIteration(uint32_t iteration) { check(pt_set_iteration(handle_, iteration)); }
+    void SetRowBands(uint32_t bandRows, uint32_t rank, uint32_t world) { check(pt_set_row_bands(handle_, bandRows, rank, world)); }
+    uint64_t RayCount() const { uint64_t v = 0; check(pt_ray_count(handle_, &v)); return v; }
     void Release()
     {
         if (handle_) { pt_destroy(handle_); handle_ = nullptr; }

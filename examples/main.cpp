@@ -8,12 +8,21 @@
 //   pt_headless [--scene demo|synth10k|mixed|FILE] [--width W] [--height H] [--iterations N]
 //               [--depth D] [--seed S] [--batch B] [--accel auto|brute] [--out image.ppm|image.pfm]
 //               [--checkpoint FILE] [--resume FILE] [--dump-scene]
+//               [--gpus N] [--split tile|sample] [--plan]
 //
 // --iterations N   render until the iteration counter reaches N (4 samples per pixel each)
 // --batch B        iterations per launch (default 16; 1 = one Run() per iteration like Display())
 // --checkpoint F   write frame buffer + iteration counter to F when done
 // --resume F       start from a checkpoint written with the same size, depth and seed
 // --dump-scene     print the scene in the scene-file format and exit (touches no GPU)
+// --gpus N         shard the render over devices 0..N-1 of this node: one host thread and one
+//                  Pathtracer per device, one RCCL reduce(sum) of the accumulation buffers into
+//                  device 0 at the end (host/multi_gpu.hpp).  N = 1 goes through the same path
+//                  (a communicator of one) when --split is given.
+// --split S        tile: 16-row bands dealt round robin, bit-identical to one GPU (default);
+//                  sample: contiguous blocks of iterations, summed and scaled
+// --plan           print which rows and iterations each device would render and exit (no GPU)
+#include "multi_gpu.hpp"
 #include "pathtracer.hpp"
 #include "scene_file.hpp"
 
@@ -56,7 +65,8 @@ static int usage(const char *msg)
     fprintf(stderr, "pt_headless: %s\n"
             "usage: pt_headless [--scene demo|synth10k|mixed|FILE] [--width W] [--height H] [--iterations N]\n"
             "                   [--depth D] [--seed S] [--batch B] [--accel auto|brute] [--out image.ppm|image.pfm]\n"
-            "                   [--checkpoint FILE] [--resume FILE] [--dump-scene]\n", msg);
+            "                   [--checkpoint FILE] [--resume FILE] [--dump-scene]\n"
+            "                   [--gpus N] [--split tile|sample] [--plan]\n", msg);
     return 2;
 }
 
@@ -73,12 +83,15 @@ int main(int argc, char **argv)
     int bounces = 10;                     // main.cpp:177
     uint64_t seed = 1;
     int accel = PT_ACCEL_AUTO;
-    bool dump = false;
+    bool dump = false, plan_only = false, split_given = false;
+    uint32_t gpus = 1;
+    SplitMode split = SplitMode::Tile;
     std::string scene = "demo", out = "pt_headless.ppm", checkpoint, resume;
 
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--dump-scene") { dump = true; continue; }
+        if (a == "--plan") { plan_only = true; continue; }
         if (i + 1 >= argc) return usage(("missing value after " + a).c_str());
         const char *v = argv[++i];
         char *end = nullptr;
@@ -98,6 +111,13 @@ int main(int argc, char **argv)
             else if (!strcmp(v, "brute")) accel = PT_ACCEL_BRUTE_FORCE;
             else return usage("--accel takes auto or brute");
         }
+        else if (a == "--split") {
+            if (!strcmp(v, "tile")) split = SplitMode::Tile;
+            else if (!strcmp(v, "sample")) split = SplitMode::Sample;
+            else return usage("--split takes tile or sample");
+            split_given = true;
+        }
+        else if (a == "--gpus") { if (!number(1, 64, &x)) return usage("bad --gpus"); gpus = (uint32_t)x; }
         else if (a == "--width") { if (!number(1, 65536, &x)) return usage("bad --width"); width = (uint32_t)x; }
         else if (a == "--height") { if (!number(1, 65536, &x)) return usage("bad --height"); height = (uint32_t)x; }
         else if (a == "--iterations") { if (!number(0, 1u << 30, &x)) return usage("bad --iterations"); iterations = (uint32_t)x; }
@@ -118,6 +138,37 @@ int main(int argc, char **argv)
         if (!sd.has_camera) { fprintf(stderr, "pt_headless: %s has no camera statement\n", scene.c_str()); return 1; }
     }
     if (dump) { WriteScene(stdout, sd); return 0; }
+    if (plan_only) {
+        // one line per device: rank, first iteration, iterations, then the row ranges
+        for (uint32_t r = 0; r < gpus; ++r) {
+            const ShardPlan p = MakeShardPlan(split, r, gpus, iterations, height);
+            printf("rank %u first_iteration %u iterations %u rows", r, p.first_iteration, p.n_iterations);
+            for (const auto &yy : p.rows) printf(" %u-%u", yy.first, yy.second);
+            printf("\n");
+        }
+        return 0;
+    }
+    const bool multi = gpus > 1 || split_given;
+    if (multi && (!checkpoint.empty() || !resume.empty())) return usage("--checkpoint/--resume work with one GPU only");
+
+    if (multi) {
+        try {
+            Camera camera(sd.eye, sd.look_at, sd.up, width, height, 0.f, 0.f, sd.fov);
+            const MultiGpuResult r = RenderMultiGpu(camera, bounces, seed, sd.materials, sd.primitives, sd.lights, accel,
+                                                    gpus, split, iterations, batch);
+            if (!r.ok) { fprintf(stderr, "ERROR: %s\n", r.error.c_str()); return 1; }
+            printf("Pathtracer (%.4f sps : %u) on %u GPU(s), %s split, %.3f G bounces/s\n", iterations / r.seconds, iterations,
+                   gpus, split == SplitMode::Tile ? "tile" : "sample", (double)r.rays / r.seconds / 1e9);
+            const bool ok = ends_with(out, ".pfm") ? WritePFM(out, r.image.data(), width, height)
+                                                   : WritePPM(out, r.image.data(), width, height);
+            if (!ok) { fprintf(stderr, "ERROR: cannot write %s\n", out.c_str()); return 1; }
+            printf("wrote %s\n", out.c_str());
+        } catch (const std::exception &e) {
+            fprintf(stderr, "ERROR: %s\n", e.what());
+            return 1;
+        }
+        return 0;
+    }
 
     try {
         Camera camera(sd.eye, sd.look_at, sd.up, width, height, 0.f, 0.f, sd.fov);

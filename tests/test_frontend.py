@@ -154,3 +154,67 @@ def test_cli_scene_file_renders_like_the_builtin_scene(exe, tmp_path):
     run(exe, *common, "--scene", scene, "--out", b)
     assert a.read_bytes() == b.read_bytes()
     assert read_pfm(a).tobytes() == g["image"].tobytes()
+
+
+def parse_plan(text):
+    out = []
+    for line in text.splitlines():
+        f = line.split()
+        assert f[0] == "rank" and f[2] == "first_iteration" and f[4] == "iterations" and f[6] == "rows"
+        out.append((int(f[1]), int(f[3]), int(f[5]), [tuple(map(int, r.split("-"))) for r in f[7:]]))
+    return out
+
+
+@pytest.mark.parametrize("world,height,iterations", [(8, 2160, 1024), (8, 1080, 64), (3, 100, 64), (2, 16, 1), (5, 48, 3)])
+def test_multi_gpu_partition_matches_the_python_sharding(exe, world, height, iterations):
+    """`pt_headless --plan` (host/multi_gpu.hpp) against sharding.owned_bands / sample_range: the
+    C++ and the Python front end cut a render the same way, every row and every iteration is
+    rendered exactly once."""
+    import importlib
+    sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
+    common = ["--plan", "--gpus", world, "--height", height, "--iterations", iterations]
+    tile = parse_plan(run(exe, *common, "--split", "tile").stdout)
+    assert len(tile) == world
+    seen = np.zeros(height, int)
+    for rank, first, n, rows in tile:
+        assert (first, n) == (1, iterations)
+        assert rows == sharding.owned_bands(height, 16, rank, world)
+        for y0, y1 in rows:
+            seen[y0:y1] += 1
+    assert (seen == 1).all()
+    sample = parse_plan(run(exe, *common, "--split", "sample").stdout)
+    covered = np.zeros(iterations + 1, int)
+    for rank, first, n, rows in sample:
+        assert rows == [(0, height)]
+        covered[first:first + n] += 1
+        if iterations % world == 0:
+            assert (first, n) == sharding.sample_range(rank, world, iterations // world)
+    assert (covered[1:] == 1).all() and covered[0] == 0
+    sizes = [n for _, _, n, _ in sample]
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_multi_gpu_usage_errors(exe, tmp_path):
+    for args in (["--gpus", "0"], ["--split", "rows"], ["--gpus", "2", "--checkpoint", tmp_path / "c.ckp"]):
+        p = run(exe, *args, check=False)
+        assert p.returncode == 2 and "usage:" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_multi_gpu_path_on_one_gpu(exe, tmp_path):
+    """The sharded render path of the front end -- host thread per device, RCCL communicator,
+    ncclReduce(sum) of the accumulation buffers -- with a communicator of one (all a one-GPU box
+    can run): the tile split is the golden image bit for bit, the sample split sums in another
+    order (rtol 2e-6 * sqrt(n) + atol 1e-6, as for PT_ACCUM_SUM elsewhere)."""
+    g = load_golden("demo_64x48_d8_it1-4")
+    common = ["--width", 64, "--height", 48, "--depth", int(g["max_bounces"]), "--seed", int(g["seed"]), "--iterations", 4,
+              "--gpus", 1]
+    tile, sample = tmp_path / "tile.pfm", tmp_path / "sample.pfm"
+    p = run(exe, *common, "--split", "tile", "--out", tile)
+    assert "on 1 GPU(s), tile split" in p.stdout
+    assert read_pfm(tile).tobytes() == g["image"].tobytes()
+    run(exe, *common, "--split", "sample", "--batch", 3, "--out", sample)
+    np.testing.assert_allclose(read_pfm(sample), g["image"], rtol=2e-6 * 2, atol=1e-6)
+    # more devices than the box has: a clean error, no crash
+    p = run(exe, *common[:-1], 64, "--split", "tile", "--out", tile, check=False)
+    assert p.returncode == 1 and "visible" in p.stderr
