@@ -42,6 +42,7 @@ SCENE_DEMO, SCENE_SYNTH10K, SCENE_MIXED = 0, 1, 2
 VARIANT_AUTO, VARIANT_REGENERATION, VARIANT_CLASSIC, VARIANT_WAVEFRONT, VARIANT_STEALING = -1, 0, 1, 100, 500
 ACCEL_AUTO, ACCEL_BRUTE_FORCE = 0, 1
 INTEGRATOR_PATH, INTEGRATOR_NEE_MIS = 0, 1
+TUNE_REGEN_MIN_IDLE, TUNE_CAMERA_RAY_RING, TUNE_STEAL_UNIT, TUNE_ITERATION_RANGES, TUNE_WAVEFRONT_REFILL = 0, 1, 2, 3, 4
 PT_OK, PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_DEVICE, PT_ERR_NOMEM = 0, -1, -2, -3, -4
 
 # Every symbol include/ptmi.h declares: (name, restype, argtypes)
@@ -65,6 +66,9 @@ ABI = [
     ("pt_ray_count", _i32, [_vp, _pu64]),
     ("pt_reset_counters", _i32, [_vp]),
     ("pt_set_kernel_variant", _i32, [_vp, _i32]),
+    ("pt_debug_set_tuning", _i32, [_vp, _i32, _i32]),
+    ("pt_memory_footprint", _i32, [_vp, _u32, _pu64]),
+    ("pt_set_memory_limit", _i32, [_vp, _u64]),
     ("pt_save_checkpoint", _i32, [_vp, _vp, ctypes.c_char_p]),
     ("pt_load_checkpoint", _i32, [_vp, _vp, ctypes.c_char_p]),
     ("pt_set_integrator", _i32, [_vp, _i32]),
@@ -304,7 +308,41 @@ class Pathtracer:
         self._check(self._lib.pt_set_row_bands(self._h, band_rows, rank, world))
 
     def SetKernelVariant(self, variant: int) -> None:
-        self._check(self._lib.pt_set_kernel_variant(self._h, variant))
+        """One of the VARIANT_* values.  Tests and tools also pass the shorthand codes of the
+        tuning experiments, which are spelled out here as a variant plus pt_debug_set_tuning calls:
+        2..64 regeneration once that many lanes are idle; 300 / 301 camera-ray ring off / on;
+        500 + 1 stealing without the ring, + 2 / + 3 single paths / whole pixel-iterations change
+        hands, + 10 + k: k + 1 iteration ranges; 100 + 1 wavefront with static assignment,
+        100 + k (k >= 2) refill threshold k."""
+        base, tunings = variant, []
+        if 2 <= variant <= 64:
+            base, tunings = VARIANT_REGENERATION, [(TUNE_REGEN_MIN_IDLE, variant)]
+        elif variant in (300, 301):
+            base, tunings = VARIANT_REGENERATION, [(TUNE_CAMERA_RAY_RING, variant - 300)]
+        elif VARIANT_WAVEFRONT < variant <= VARIANT_WAVEFRONT + 64:
+            k = variant - VARIANT_WAVEFRONT
+            base, tunings = VARIANT_WAVEFRONT, [(TUNE_WAVEFRONT_REFILL, 0 if k == 1 else k)]
+        elif variant == VARIANT_STEALING + 1:
+            base, tunings = VARIANT_STEALING, [(TUNE_CAMERA_RAY_RING, 0)]
+        elif variant in (VARIANT_STEALING + 2, VARIANT_STEALING + 3):
+            base, tunings = VARIANT_STEALING, [(TUNE_STEAL_UNIT, 1 if variant == VARIANT_STEALING + 2 else 4)]
+        elif VARIANT_STEALING + 10 <= variant <= VARIANT_STEALING + 26:
+            base, tunings = VARIANT_STEALING, [(TUNE_ITERATION_RANGES, variant - (VARIANT_STEALING + 10) + 1)]
+        self._check(self._lib.pt_set_kernel_variant(self._h, base))
+        for key, value in tunings:
+            self.SetTuning(key, value)
+
+    def SetTuning(self, key: int, value: int) -> None:
+        self._check(self._lib.pt_debug_set_tuning(self._h, key, value))
+
+    def MemoryFootprint(self, n_iterations: int = 0):
+        """(bytes held now, bytes at the peak of a RunN(n_iterations))."""
+        out = (_u64 * 2)()
+        self._check(self._lib.pt_memory_footprint(self._h, n_iterations, out))
+        return int(out[0]), int(out[1])
+
+    def SetMemoryLimit(self, n_bytes: int) -> None:
+        self._check(self._lib.pt_set_memory_limit(self._h, n_bytes))
 
     def SetIntegrator(self, integrator: int) -> None:
         """INTEGRATOR_PATH: the reference's Trace; INTEGRATOR_NEE_MIS: plus direct-light sampling."""

@@ -7,6 +7,7 @@
 #include "ptmi.h"
 #include "pt_kernels.hpp"
 #include "pt_bvh.hpp"
+#include "pt_checkpoint.hpp"
 
 #include <cstdarg>
 #include <cstdio>
@@ -35,6 +36,8 @@ struct pt_context {
     int integrator;       // PT_INTEGRATOR_*
     uint32_t n_prims, n_mats, n_lights;
     bool scene_ready;
+    uint64_t scene_hash;  // fingerprint of the arrays given to pt_init_scene (checkpoints)
+    uint64_t scene_bytes; // device memory of the scene arrays and the BVH
     // sphere BVH of scenes too large for LDS residency (device); n_nodes == 0: none
     BvhParams bvh;
     void *d_bvh;          // one allocation behind the pointers in `bvh`
@@ -158,6 +161,8 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->integrator = PT_INTEGRATOR_PATH;
     h->n_prims = h->n_mats = h->n_lights = 0;
     h->scene_ready = false;
+    h->scene_hash = 0;
+    h->scene_bytes = 0;
     memset(&h->bvh, 0, sizeof h->bvh);
     h->d_bvh = nullptr;
     h->accel = PT_ACCEL_AUTO;
@@ -213,6 +218,7 @@ static void free_scene(pt_context *h)
     h->d_bvh = nullptr;
     memset(&h->bvh, 0, sizeof h->bvh);
     h->scene_ready = false;
+    h->scene_bytes = 0;
 }
 
 // Build the sphere BVH on the host and upload it as one allocation.
@@ -241,6 +247,7 @@ static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sp
     }
     PT_HIP(h, hipMalloc(&h->d_bvh, total));
     PT_HIP(h, hipMemcpy(h->d_bvh, blob.data(), total, hipMemcpyHostToDevice));
+    h->scene_bytes += total;
     const unsigned char *base = (const unsigned char *)h->d_bvh;
     h->bvh.nodes = (const float4 *)(base + off_nodes);
     h->bvh.leaf_sph = (const float4 *)(base + off_ls);
@@ -368,9 +375,19 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
                     hipGetErrorString(ue));
     }
     h->n_prims = n_spheres; h->n_mats = n_materials; h->n_lights = n_lights;
+    h->scene_bytes = (sph.size() + aux.size() + mat.size() + light.size() + light_geom.size()) * sizeof(float4) +
+                     mtype.size() * sizeof(int);
     if (n_spheres > kBvhMinSpheres) {
         const int rc = upload_bvh(h, sph, spheres, n_spheres);
         if (rc != PT_OK) { free_scene(h); return rc; }
+    }
+    // fingerprint for checkpoints; of a light only the union member its type selects counts
+    h->scene_hash = fingerprint(spheres, n_spheres * sizeof(pt_sphere), fingerprint(materials, n_materials * sizeof(pt_material)));
+    for (uint32_t i = 0; i < n_lights; ++i) {
+        h->scene_hash = fingerprint(&lights[i].type, sizeof lights[i].type, h->scene_hash);
+        if (lights[i].type == PT_POINT_LIGHT) h->scene_hash = fingerprint(lights[i].u.pos, sizeof lights[i].u.pos, h->scene_hash);
+        else if (lights[i].type == PT_AREA_LIGHT) h->scene_hash = fingerprint(&lights[i].u.prim_id, sizeof(uint32_t), h->scene_hash);
+        h->scene_hash = fingerprint(lights[i].intensity, sizeof lights[i].intensity, h->scene_hash);
     }
     h->scene_ready = true;
     return PT_OK;
@@ -503,33 +520,93 @@ int pt_lane_stats(pt_handle h, uint64_t out[64])
 int pt_set_kernel_variant(pt_handle h, int variant)
 {
     if (!h) return PT_ERR_INVALID;
-    h->wavefront = false;
-    h->auto_variant = false;
+    if (variant != PT_VARIANT_AUTO && variant != PT_VARIANT_REGENERATION && variant != PT_VARIANT_CLASSIC &&
+        variant != PT_VARIANT_WAVEFRONT && variant != PT_VARIANT_STEALING)
+        return fail(h, PT_ERR_INVALID, "pt_set_kernel_variant: unknown variant %d", variant);
+    // every tuning knob back to its default
     h->small_scene_opts = 1;
-    h->steal = false;
     h->chunks = 0;
     h->steal_unit = 0;
     h->wf_dynamic_fetch = 32;
-    if (variant == PT_VARIANT_AUTO) { h->auto_variant = true; h->regen_min_idle = 1; h->steal = true; }
-    else if (variant >= PT_VARIANT_WAVEFRONT && variant <= PT_VARIANT_WAVEFRONT + 64) {
-        // +1: static assignment of paths to lanes; +2..+64: refill threshold of the dynamic fetch (A/B)
-        h->wavefront = true;
-        const int k = variant - PT_VARIANT_WAVEFRONT;
-        h->wf_dynamic_fetch = k == 0 ? 32 : (k == 1 ? 0 : k);
+    h->regen_min_idle = variant == PT_VARIANT_CLASSIC ? 64 : 1;
+    h->auto_variant = variant == PT_VARIANT_AUTO;
+    h->wavefront = variant == PT_VARIANT_WAVEFRONT;
+    h->steal = variant == PT_VARIANT_AUTO || variant == PT_VARIANT_STEALING;
+    return PT_OK;
+}
+
+int pt_debug_set_tuning(pt_handle h, int key, int value)
+{
+    if (!h) return PT_ERR_INVALID;
+    switch (key) {
+    case PT_TUNE_REGEN_MIN_IDLE:
+        if (value < 1 || value > 64) break;
+        h->regen_min_idle = value;
+        return PT_OK;
+    case PT_TUNE_CAMERA_RAY_RING:
+        if (value != 0 && value != 1) break;
+        h->small_scene_opts = value;
+        return PT_OK;
+    case PT_TUNE_STEAL_UNIT:
+        if (value != 0 && value != 1 && value != 4) break;
+        h->steal_unit = value;
+        return PT_OK;
+    case PT_TUNE_ITERATION_RANGES:
+        if (value < 0 || value > 32) break;
+        h->chunks = value;
+        return PT_OK;
+    case PT_TUNE_WAVEFRONT_REFILL:
+        if (value < 0 || value > 64) break;
+        h->wf_dynamic_fetch = value;
+        return PT_OK;
+    default:
+        return fail(h, PT_ERR_INVALID, "pt_debug_set_tuning: unknown key %d", key);
     }
-    else if (variant >= 300 && variant <= 301) { h->regen_min_idle = 1; h->small_scene_opts = variant - 300; } // experiments
-    else if (variant == PT_VARIANT_STEALING) { h->regen_min_idle = 1; h->steal = true; }
-    else if (variant >= PT_VARIANT_STEALING + 10 && variant <= PT_VARIANT_STEALING + 26) { // experiments: iteration ranges
-        h->regen_min_idle = 1; h->steal = true; h->chunks = variant - (PT_VARIANT_STEALING + 10) + 1;
+    return fail(h, PT_ERR_INVALID, "pt_debug_set_tuning: value %d out of range for key %d", value, key);
+}
+
+static uint32_t div_up(uint32_t a, uint32_t b);
+static uint32_t auto_chunks(uint64_t tiles, uint32_t n_iterations);
+static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_per_it, uint32_t n_iterations);
+static bool takes_wavefront(const pt_context *h, uint64_t last_iteration);
+
+int pt_set_memory_limit(pt_handle h, uint64_t bytes)
+{
+    if (!h) return PT_ERR_INVALID;
+    h->memory_limit = bytes;
+    h->steal_alloc_failed = false;   // a raised limit may allow the scratch pool after all
+    return PT_OK;
+}
+
+int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
+{
+    if (!h || !bytes) return PT_ERR_INVALID;
+    const uint64_t frame = (uint64_t)h->camera.width * h->camera.height * 3 * sizeof(float);
+    const uint64_t fixed = sizeof(unsigned long long) + h->scene_bytes + (h->d_internal_buffer ? frame : 0);
+    const uint64_t steal_now = h->d_steal ? kStealPoolBytes + kStealMaskBytes : 0;
+    const uint64_t tickets_now = (uint64_t)h->tickets_capacity * sizeof(uint32_t);
+    const uint64_t counts = (uint64_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
+    const uint64_t wf_now = h->wf_counts ? (uint64_t)h->wf_sub_capacity * kWfSubQueues * 2 * (3 * sizeof(float4) + sizeof(uint2)) +
+                                               h->wf_capacity * 3 * sizeof(float) + counts : 0;
+    bytes[0] = fixed + steal_now + tickets_now + wf_now;
+    // what the next render adds: wavefront queues of one batch, or the scratch pool and tickets
+    uint64_t steal_next = steal_now, tickets_next = tickets_now, wf_next = wf_now;
+    const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
+    const uint32_t batch_it = n_iterations ? wavefront_batch_iterations(h, paths_per_it, n_iterations) : 0;
+    if (n_iterations && h->scene_ready && takes_wavefront(h, h->iteration + (uint64_t)n_iterations) && batch_it > 0) {
+        const uint64_t capacity = paths_per_it * batch_it;
+        const uint64_t sub_cap = ((capacity + 255) / 256 + kWfSubQueues - 1) / kWfSubQueues * 256;
+        const uint64_t need = sub_cap * kWfSubQueues * 2 * (3 * sizeof(float4) + sizeof(uint2)) + capacity * 3 * sizeof(float) + counts;
+        if (need > wf_next) wf_next = need;
+    } else if (n_iterations && h->scene_ready && !h->wavefront && h->steal && !h->steal_alloc_failed &&
+               (!h->memory_limit || kStealPoolBytes + kStealMaskBytes <= h->memory_limit)) {
+        steal_next = kStealPoolBytes + kStealMaskBytes;
+        const uint64_t tiles = (uint64_t)div_up(h->camera.width, 16) * div_up(h->camera.height, 16);
+        uint32_t n_chunks = h->chunks > 0 ? (uint32_t)h->chunks : auto_chunks(tiles, n_iterations);
+        if (n_chunks > n_iterations / 4) n_chunks = n_iterations / 4;
+        if (n_chunks > 1 && (1 + tiles) * sizeof(uint32_t) > tickets_next) tickets_next = (1 + tiles) * sizeof(uint32_t);
     }
-    else if (variant == PT_VARIANT_STEALING + 2 || variant == PT_VARIANT_STEALING + 3) { // experiments: unit of 1 / 4 paths
-        h->regen_min_idle = 1; h->steal = true; h->steal_unit = variant == PT_VARIANT_STEALING + 2 ? 1 : 4;
-    }
-    else if (variant == PT_VARIANT_STEALING + 1) { h->regen_min_idle = 1; h->small_scene_opts = 0; h->steal = true; } // experiment: no ring
-    else if (variant == 0) h->regen_min_idle = 1;
-    else if (variant == 1) h->regen_min_idle = 64;
-    else if (variant >= 2 && variant <= 64) h->regen_min_idle = variant; // experimental: idle-lane threshold
-    else return fail(h, PT_ERR_INVALID, "pt_set_kernel_variant: unknown variant %d", variant);
+    bytes[1] = fixed + steal_next + tickets_next + wf_next;
     return PT_OK;
 }
 
@@ -918,42 +995,33 @@ int pt_read_image(pt_handle h, const float *device_buffer, float *host_rgb)
 }
 
 // ---- checkpoint / resume ---------------------------------------------------------------------
-// File: 64-byte header + width*height*3 floats.  With the counter-based RNG the triple
-// (frame buffer, iteration, seed) is the whole state of a render.
-namespace {
-struct CheckpointHeader {
-    char magic[8];        // "PTMICKP1"
-    uint32_t width, height;
-    uint32_t iteration;
-    int32_t max_bounces;
-    uint64_t seed;
-    int32_t accum_mode;
-    uint32_t reserved[7];
-};
-static_assert(sizeof(CheckpointHeader) == 64, "checkpoint header layout");
-const char kCheckpointMagic[8] = {'P', 'T', 'M', 'I', 'C', 'K', 'P', '1'};
+// File format and checks: pt_checkpoint.cpp (host code).  Here: the instance's side of it.
+static CheckpointMeta checkpoint_meta(const pt_context *h)
+{
+    CheckpointMeta m;
+    m.width = h->camera.width; m.height = h->camera.height;
+    m.iteration = h->iteration;
+    m.max_bounces = h->max_bounces;
+    m.seed = h->seed;
+    m.accum_mode = h->accum_mode;
+    m.integrator = h->integrator;
+    m.scene_hash = h->scene_hash;
+    m.camera_hash = fingerprint(&h->camera, sizeof h->camera);
+    return m;
 }
 
 int pt_save_checkpoint(pt_handle h, const float *device_buffer, const char *path)
 {
     if (!h) return PT_ERR_INVALID;
     if (!device_buffer || !path) return fail(h, PT_ERR_INVALID, "pt_save_checkpoint: NULL argument");
+    if (!h->scene_ready) return fail(h, PT_ERR_STATE, "pt_save_checkpoint before pt_init_scene");
     const size_t n = (size_t)h->camera.width * h->camera.height * 3;
     std::vector<float> img(n);
     const int rc = pt_read_image(h, device_buffer, img.data());
     if (rc != PT_OK) return rc;
-    CheckpointHeader hd;
-    memset(&hd, 0, sizeof hd);
-    memcpy(hd.magic, kCheckpointMagic, 8);
-    hd.width = h->camera.width; hd.height = h->camera.height;
-    hd.iteration = h->iteration;
-    hd.max_bounces = h->max_bounces;
-    hd.seed = h->seed;
-    hd.accum_mode = h->accum_mode;
-    FILE *f = fopen(path, "wb");
-    if (!f) return fail(h, PT_ERR_INVALID, "pt_save_checkpoint: cannot open %s for writing", path);
-    const bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && fwrite(img.data(), sizeof(float), n, f) == n;
-    if (fclose(f) != 0 || !ok) return fail(h, PT_ERR_INVALID, "pt_save_checkpoint: short write to %s", path);
+    std::string err;
+    if (checkpoint_write(path, checkpoint_meta(h), img.data(), &err) != kCkpOk)
+        return fail(h, PT_ERR_INVALID, "pt_save_checkpoint: %s", err.c_str());
     return PT_OK;
 }
 
@@ -962,28 +1030,16 @@ int pt_load_checkpoint(pt_handle h, float *device_buffer, const char *path)
     if (!h) return PT_ERR_INVALID;
     DeviceGuard on_device(h->device);
     if (!device_buffer || !path) return fail(h, PT_ERR_INVALID, "pt_load_checkpoint: NULL argument");
-    FILE *f = fopen(path, "rb");
-    if (!f) return fail(h, PT_ERR_INVALID, "pt_load_checkpoint: cannot open %s", path);
-    CheckpointHeader hd;
-    const size_t n = (size_t)h->camera.width * h->camera.height * 3;
-    std::vector<float> img(n);
-    bool ok = fread(&hd, sizeof hd, 1, f) == 1;
-    const bool header_ok = ok && memcmp(hd.magic, kCheckpointMagic, 8) == 0;
-    const bool same = header_ok && hd.width == h->camera.width && hd.height == h->camera.height &&
-                      hd.max_bounces == h->max_bounces && hd.seed == h->seed && hd.accum_mode == h->accum_mode;
-    if (same) ok = fread(img.data(), sizeof(float), n, f) == n && fgetc(f) == EOF;
-    fclose(f);
-    if (!header_ok) return fail(h, PT_ERR_INVALID, "pt_load_checkpoint: %s is not a checkpoint", path);
-    if (!same)
-        return fail(h, PT_ERR_STATE, "pt_load_checkpoint: %s is %ux%u, depth %d, seed %llu, mode %d; this instance "
-                    "is %ux%u, depth %d, seed %llu, mode %d", path, hd.width, hd.height, hd.max_bounces,
-                    (unsigned long long)hd.seed, hd.accum_mode, h->camera.width, h->camera.height, h->max_bounces,
-                    (unsigned long long)h->seed, h->accum_mode);
-    if (!ok) return fail(h, PT_ERR_INVALID, "pt_load_checkpoint: %s is truncated or has trailing bytes", path);
-    PT_HIP(h, hipMemcpyAsync(device_buffer, img.data(), n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (!h->scene_ready) return fail(h, PT_ERR_STATE, "pt_load_checkpoint before pt_init_scene");
+    std::vector<float> img;
+    uint32_t iteration = 0;
+    std::string err;
+    const int rc = checkpoint_read(path, checkpoint_meta(h), &img, &iteration, &err);
+    if (rc != kCkpOk) return fail(h, rc == kCkpMismatch ? PT_ERR_STATE : PT_ERR_INVALID, "pt_load_checkpoint: %s", err.c_str());
+    PT_HIP(h, hipMemcpyAsync(device_buffer, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
-    h->iteration = hd.iteration;
-    h->fresh = hd.iteration == 0;
+    h->iteration = iteration;
+    h->fresh = iteration == 0;
     return PT_OK;
 }
 

@@ -157,28 +157,50 @@ int pt_ray_count(pt_handle h, uint64_t *out);
 int pt_reset_counters(pt_handle h);
 /* Kernel variant; results are bit-identical in all of them.
  *   PT_VARIANT_AUTO (default): PT_VARIANT_WAVEFRONT for scenes rendered through the sphere BVH
- *     (when no row bands are set and the integrator is PT_INTEGRATOR_PATH), else
- *     PT_VARIANT_STEALING
+ *     (when no row bands are set, the integrator is PT_INTEGRATOR_PATH and the queues fit the
+ *     memory limit), else PT_VARIANT_STEALING
  *   PT_VARIANT_STEALING: PT_VARIANT_REGENERATION, and a lane that has finished its pixel takes
  *     work over from the lane of its wave with the most left: whole pixel-iterations, or single
- *     paths in launches of up to 5 iterations (pt_run's one iteration per call: +23 %).  Applies to
- *     every megakernel launch (linear scan or BVH, either integrator); allocates 96 bytes of scratch per pixel on first use
- *     (199 MB at 1080p; frames that would need more than 4 GiB do not steal); everything else, or a
- *     failed allocation, runs PT_VARIANT_REGENERATION.
- *     Launches of 32 iterations or more over a small frame are also cut into consecutive iteration
- *     ranges rendered by separate workgroups (up to 8, at least 16 iterations each), so that fewer
- *     SIMDs idle while the last workgroups finish; + 1: no camera-ray ring, + 2 / + 3: single paths /
- *     whole pixel-iterations change hands, + 10 + k: k + 1 ranges (experiments)
+ *     paths in launches of up to 5 iterations (pt_run's one iteration per call).  Applies to every
+ *     megakernel launch (linear scan or BVH, either integrator); allocates a 48 MiB scratch pool
+ *     on first use, whatever the frame size (a failed allocation: PT_VARIANT_REGENERATION).
+ *     Launches of 32 iterations or more over a small frame are also cut into consecutive
+ *     iteration ranges rendered by separate workgroups (up to 8, at least 16 iterations each), so
+ *     that fewer SIMDs idle while the last workgroups finish
  *   PT_VARIANT_REGENERATION: megakernel, persistent lanes with path regeneration
  *   PT_VARIANT_CLASSIC: megakernel, a wave starts new paths only when all its lanes are idle
- *   2..64: megakernel, regeneration once that many lanes of a wave are idle (experiments)
  *   PT_VARIANT_WAVEFRONT: one launch per bounce over compacted path queues in device memory
- *     (allocates about 4 GiB of queues on first use; no row bands).  BVH scenes: persistent
- *     waves that refill idle lanes from the queue while the other lanes keep traversing;
- *     PT_VARIANT_WAVEFRONT + 1 switches that off, + 2..64 sets the refill threshold (experiments) */
+ *     (124 bytes per path of a batch, up to about 4 GiB, allocated on first use -- see
+ *     pt_memory_footprint; no row bands).  BVH scenes: persistent waves that refill idle lanes
+ *     from the queue while the other lanes keep traversing
+ * Selecting a variant resets the tuning knobs below to their defaults. */
 enum { PT_VARIANT_AUTO = -1, PT_VARIANT_REGENERATION = 0, PT_VARIANT_CLASSIC = 1, PT_VARIANT_WAVEFRONT = 100,
        PT_VARIANT_STEALING = 500 };
 int pt_set_kernel_variant(pt_handle h, int variant);
+/* Tuning knobs of the kernels, for measurements and tests (results stay bit-identical); not
+ * part of the drop-in surface.  Call after pt_set_kernel_variant.
+ *   PT_TUNE_REGEN_MIN_IDLE     1..64: idle lanes a wave waits for before it starts new paths
+ *                              (1: PT_VARIANT_REGENERATION's default, 64: PT_VARIANT_CLASSIC)
+ *   PT_TUNE_CAMERA_RAY_RING    0/1: per-lane ring of pre-generated camera rays in LDS (scenes of
+ *                              up to 24 spheres; default 1)
+ *   PT_TUNE_STEAL_UNIT         0: chosen per launch; 1 / 4: single paths / whole pixel-iterations
+ *                              change hands
+ *   PT_TUNE_ITERATION_RANGES   0: chosen per launch; n: a launch is cut into n iteration ranges
+ *   PT_TUNE_WAVEFRONT_REFILL   BVH scenes: lanes still traversing below which a persistent wave
+ *                              refills (default 32); 0: static assignment of paths to lanes */
+enum { PT_TUNE_REGEN_MIN_IDLE = 0, PT_TUNE_CAMERA_RAY_RING = 1, PT_TUNE_STEAL_UNIT = 2, PT_TUNE_ITERATION_RANGES = 3,
+       PT_TUNE_WAVEFRONT_REFILL = 4 };
+int pt_debug_set_tuning(pt_handle h, int key, int value);
+/* Device memory held by the instance: bytes[0] = allocated now (scene, BVH, scratch pool,
+ * tickets, wavefront queues, internal frame buffer); bytes[1] = what a pt_run_n of n_iterations
+ * would hold at its peak with the current settings.  The statically allocated scratch of
+ * pt_run_n_noalloc (48.3 MiB per GPU, per process) is not included. */
+int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2]);
+/* Upper bound, in bytes, on what the instance allocates for scratch and queues (0: none, the
+ * default).  The wavefront variant sizes its batches to fit -- or, under PT_VARIANT_AUTO, leaves
+ * the render to the megakernel when not even one iteration's queues fit (PT_VARIANT_WAVEFRONT
+ * itself then fails with PT_ERR_NOMEM); a limit below 48 MiB also switches work stealing off. */
+int pt_set_memory_limit(pt_handle h, uint64_t bytes);
 /* Integrator.
  *   PT_INTEGRATOR_PATH (default): Trace as the reference runs it, pathtracer.cu:112-170.
  *   PT_INTEGRATOR_NEE_MIS: adds direct-light sampling with multiple importance sampling, wiring

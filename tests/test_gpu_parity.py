@@ -416,6 +416,31 @@ def test_checkpoint_resume_is_bit_exact(pt, torch_cuda, tmp_path):
     with pytest.raises(pt.PtError) as e:
         other.LoadCheckpoint(buf2, path)          # different seed
     assert e.value.code == pt.PT_ERR_STATE and "seed" in str(e.value)
+    # the conditions the frame was rendered under are part of the file: another integrator,
+    # another scene or another camera is refused as well
+    same = make_tracer(pt, g)
+    same.SetAccumMode(pt.ACCUM_SUM)
+    same.SetIntegrator(pt.INTEGRATOR_NEE_MIS)
+    with pytest.raises(pt.PtError) as e:
+        same.LoadCheckpoint(buf2, path)
+    assert e.value.code == pt.PT_ERR_STATE and "integrator" in str(e.value)
+    same.SetIntegrator(pt.INTEGRATOR_PATH)
+    moved = g["spheres"].copy()
+    moved["pos"][6, 0] += 1.0
+    same.Init(g["materials"], moved, g["lights"])
+    with pytest.raises(pt.PtError) as e:
+        same.LoadCheckpoint(buf2, path)
+    assert e.value.code == pt.PT_ERR_STATE and "scene" in str(e.value)
+    same.Init(g["materials"], g["spheres"], g["lights"])
+    same.SetCamera(pt.Camera([5, 40, 70], g["look_at"], g["up"], 64, 48, 0, 0, float(g["fov"])))
+    with pytest.raises(pt.PtError) as e:
+        same.LoadCheckpoint(buf2, path)
+    assert e.value.code == pt.PT_ERR_STATE and "camera" in str(e.value)
+    same.SetCamera(g["camera_pod"])
+    same.LoadCheckpoint(buf2, path)
+    assert same.GetIteration() == 2
+    same.Release()
+    assert not __import__("os").path.exists(path + ".tmp")
     blob = open(path, "rb").read()
     open(path, "wb").write(blob[:-5])
     c = make_tracer(pt, g)
@@ -631,3 +656,73 @@ def make_wavefront_image(pt, torch, cam, mats, sph, lights, depth):
     img = render(torch, tr, 1, 1).cpu().numpy().reshape(cam.Height(), cam.Width(), 3)
     tr.Release()
     return img
+
+
+def test_variants_tuning_and_memory_footprint(pt, torch_cuda):
+    """pt_set_kernel_variant takes the five named variants only, experiments go through
+    pt_debug_set_tuning; pt_memory_footprint predicts what a render allocates; pt_set_memory_limit
+    bounds the wavefront queues (PT_VARIANT_AUTO then renders the same image with the megakernel)."""
+    lib = pt.load_library()
+    g = load_golden("demo_64x48_d8_it1-4")
+    tr = make_tracer(pt, g, pt.VARIANT_AUTO)
+    for bad in (7, 64, 101, 300, 501, 513, -2):
+        assert lib.pt_set_kernel_variant(tr._h, bad) == pt.PT_ERR_INVALID
+    for key, value in ((pt.TUNE_REGEN_MIN_IDLE, 0), (pt.TUNE_REGEN_MIN_IDLE, 65), (pt.TUNE_STEAL_UNIT, 2), (pt.TUNE_CAMERA_RAY_RING, 2),
+                       (pt.TUNE_ITERATION_RANGES, 33), (pt.TUNE_WAVEFRONT_REFILL, 65), (99, 0)):
+        assert lib.pt_debug_set_tuning(tr._h, key, value) == pt.PT_ERR_INVALID
+    tr.SetKernelVariant(pt.VARIANT_STEALING)
+    tr.SetTuning(pt.TUNE_ITERATION_RANGES, 2)
+    tr.SetTuning(pt.TUNE_STEAL_UNIT, 4)
+    img = render(torch_cuda, tr, 1, 4).cpu().numpy()
+    assert img.tobytes() == g["image"].tobytes()
+    tr.Release()
+
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
+    cam = pt.Camera(eye, look, up, 640, 360, 0, 0, fov)
+    tr = pt.Pathtracer(cam, 8, 1)
+    tr.Init(mats, sph, lights)
+    now, nxt = tr.MemoryFootprint(64)
+    pool = 48 * 2**20 + 1024
+    tiles = 40 * 23
+    assert now < 4096 and nxt == now + pool + 4 * (1 + tiles)
+    assert tr.MemoryFootprint(4) == (now, now + pool)              # a short launch is not cut into ranges
+    buf = torch_cuda.zeros(640 * 360 * 3, device="cuda")
+    tr.RunN(buf, 64)
+    assert tr.MemoryFootprint(64) == (nxt, nxt)
+    # the footprint does not grow with the frame: a 4K instance predicts the same pool
+    cam4k = pt.Camera(eye, look, up, 3840, 2160, 0, 0, fov)
+    big = pt.Pathtracer(cam4k, 8, 1)
+    big.Init(mats, sph, lights)
+    b_now, b_next = big.MemoryFootprint(16)
+    assert b_next - b_now == pool
+    big.SetMemoryLimit(2**20)                                      # no room for the pool: no stealing, nothing allocated
+    assert big.MemoryFootprint(16) == (b_now, b_now)
+    big.Release()
+    tr.Release()
+
+    # BVH scene: PT_VARIANT_AUTO takes the wavefront queues, 124 bytes per path of a batch
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_SYNTH10K, 1)
+    cam = pt.Camera(eye, look, up, 256, 128, 0, 0, fov)
+    tr = pt.Pathtracer(cam, 8, 1)
+    tr.Init(mats, sph, lights)
+    now, nxt = tr.MemoryFootprint(2)
+    paths = 256 * 128 * 4 * 2
+    assert 124 * paths <= nxt - now <= 124 * paths + 2**20
+    ref = render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes()
+    assert tr.MemoryFootprint(2) == (nxt, nxt)
+    tr.Release()
+    tr = pt.Pathtracer(cam, 8, 1)
+    tr.Init(mats, sph, lights)
+    tr.SetMemoryLimit(124 * 256 * 128 * 4 - 1)                     # not even one iteration's queues
+    now, nxt = tr.MemoryFootprint(2)
+    assert nxt == now                                              # below 48 MiB: no scratch pool either
+    assert render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes() == ref     # rendered by the BVH megakernel
+    assert tr.MemoryFootprint(2)[0] == now
+    tr.SetKernelVariant(pt.VARIANT_WAVEFRONT)
+    with pytest.raises(pt.PtError) as e:
+        tr.RunN(torch_cuda.zeros(256 * 128 * 3, device="cuda"), 1)
+    assert e.value.code == pt.PT_ERR_NOMEM
+    tr.SetMemoryLimit(124 * 256 * 128 * 4 + 2**20)                 # one iteration per batch
+    tr.SetKernelVariant(pt.VARIANT_AUTO)
+    assert render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes() == ref
+    tr.Release()

@@ -11,6 +11,24 @@
 #include <cstdlib>
 #include <vector>
 
+// The shorthand codes of the tuning experiments (a variant plus one pt_debug_set_tuning call):
+// 2..64 regeneration threshold, 300 / 301 camera-ray ring off / on, 500 + 1 stealing without the
+// ring, + 2 / + 3 unit of 1 / 4 paths, + 10 + k: k + 1 iteration ranges, 100 + 1 static wavefront,
+// 100 + k refill threshold k.
+static int set_variant(pt_handle h, int v)
+{
+    int base = v, key = -1, value = 0;
+    if (v >= 2 && v <= 64) { base = PT_VARIANT_REGENERATION; key = PT_TUNE_REGEN_MIN_IDLE; value = v; }
+    else if (v == 300 || v == 301) { base = PT_VARIANT_REGENERATION; key = PT_TUNE_CAMERA_RAY_RING; value = v - 300; }
+    else if (v > PT_VARIANT_WAVEFRONT && v <= PT_VARIANT_WAVEFRONT + 64) { base = PT_VARIANT_WAVEFRONT; key = PT_TUNE_WAVEFRONT_REFILL; value = v - 100 == 1 ? 0 : v - 100; }
+    else if (v == PT_VARIANT_STEALING + 1) { base = PT_VARIANT_STEALING; key = PT_TUNE_CAMERA_RAY_RING; value = 0; }
+    else if (v == PT_VARIANT_STEALING + 2 || v == PT_VARIANT_STEALING + 3) { base = PT_VARIANT_STEALING; key = PT_TUNE_STEAL_UNIT; value = v == PT_VARIANT_STEALING + 2 ? 1 : 4; }
+    else if (v >= PT_VARIANT_STEALING + 10 && v <= PT_VARIANT_STEALING + 26) { base = PT_VARIANT_STEALING; key = PT_TUNE_ITERATION_RANGES; value = v - (PT_VARIANT_STEALING + 10) + 1; }
+    int rc = pt_set_kernel_variant(h, base);
+    if (rc == PT_OK && key >= 0) rc = pt_debug_set_tuning(h, key, value);
+    return rc;
+}
+
 int main(int argc, char **argv)
 {
     const int scene = argc > 1 ? atoi(argv[1]) : 0;
@@ -44,7 +62,7 @@ int main(int argc, char **argv)
         const int variant = variants[r % variants.size()];
         pt_set_accel(hd, variant % 2000 >= 1000 ? PT_ACCEL_BRUTE_FORCE : PT_ACCEL_AUTO);
         pt_set_integrator(hd, variant >= 2000 ? PT_INTEGRATOR_NEE_MIS : PT_INTEGRATOR_PATH);
-        if (pt_set_kernel_variant(hd, variant % 1000) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
+        if (set_variant(hd, variant % 1000) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
         pt_reset(hd); pt_reset_counters(hd);
         const auto t0 = std::chrono::steady_clock::now();
         if (pt_run_n(hd, buf, iters, 1) != PT_OK) { printf("%s\n", pt_last_error(hd)); return 1; }
