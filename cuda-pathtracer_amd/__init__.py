@@ -43,6 +43,7 @@ VARIANT_AUTO, VARIANT_REGENERATION, VARIANT_CLASSIC, VARIANT_WAVEFRONT, VARIANT_
 ACCEL_AUTO, ACCEL_BRUTE_FORCE = 0, 1
 INTEGRATOR_PATH, INTEGRATOR_NEE_MIS = 0, 1
 TUNE_REGEN_MIN_IDLE, TUNE_CAMERA_RAY_RING, TUNE_STEAL_UNIT, TUNE_ITERATION_RANGES, TUNE_WAVEFRONT_REFILL = 0, 1, 2, 3, 4
+TUNE_BVH_NODE_STEPS, TUNE_BVH_STACK = 5, 6
 PT_OK, PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_DEVICE, PT_ERR_NOMEM = 0, -1, -2, -3, -4
 
 # Every symbol include/ptmi.h declares: (name, restype, argtypes)
@@ -218,8 +219,9 @@ def build_scene(scene_id: int = SCENE_DEMO, seed: int = 1):
 
 def debug_build_bvh(spheres):
     """Host-side BVH of `spheres` as pt_init_scene would build it (no device needed).
-    Returns None when no hierarchy is built, else a dict: nodes [n,16] float32 (child boxes and
-    references, device layout), leaf_index [leaves,4], big_index, depth."""
+    Returns None when no hierarchy is built, else a dict: nodes [n,32] float32 (four-wide nodes in
+    device layout: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] refs[4] pad[4]), leaf_index
+    [leaves,4], big_index, depth (wide levels)."""
     lib = load_library()
     sph = np.ascontiguousarray(spheres, SPHERE_DTYPE)
     counts = (_u32 * 4)()
@@ -227,7 +229,7 @@ def debug_build_bvh(spheres):
         raise ValueError("pt_debug_build_bvh: invalid arguments")
     if counts[0] == 0:
         return None
-    nodes = np.zeros((counts[0], 16), np.float32)
+    nodes = np.zeros((counts[0], 32), np.float32)
     leaf = np.zeros((counts[1], 4), np.int32)
     big = np.zeros(counts[2], np.int32)
     lib.pt_debug_build_bvh(_ptr(sph), len(sph), counts, _ptr(nodes), _ptr(leaf), _ptr(big))

@@ -9,6 +9,7 @@
 #include "pt_bvh.hpp"
 #include "pt_checkpoint.hpp"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -42,6 +43,7 @@ struct pt_context {
     BvhParams bvh;
     void *d_bvh;          // one allocation behind the pointers in `bvh`
     uint32_t bvh_default_budget;
+    uint32_t bvh_default_stack;   // stack entries upload_bvh chose
     int accel;            // PT_ACCEL_*
     // misc device state
     unsigned long long *d_ray_counter;
@@ -229,7 +231,7 @@ static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sp
     BvhData d;
     if (!build_bvh(sph.data(), radius.data(), n, &d)) return PT_OK;   // brute force stays
     auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
-    const size_t n_nodes = d.nodes.size() / 4, n_slots = d.leaf_sph.size(), n_big = d.big_sph.size();
+    const size_t n_nodes = d.nodes.size() / kBvhNodeVec4, n_slots = d.leaf_sph.size(), n_big = d.big_sph.size();
     const size_t off_nodes = 0;
     const size_t off_ls = off_nodes + pad(d.nodes.size() * sizeof(float4));
     const size_t off_li = off_ls + pad(n_slots * sizeof(float4));
@@ -257,10 +259,17 @@ static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sp
     h->bvh.stats = (unsigned long long *)((unsigned char *)h->d_bvh + off_st);
     h->bvh.n_nodes = (uint32_t)n_nodes;
     h->bvh.n_big = (uint32_t)n_big;
-    h->bvh.depth = d.depth;
+    // Entries of the per-lane traversal stack (LDS, 2 KiB per entry and workgroup).  A node defers up
+    // to three children, but a ray rarely meets more than two of four boxes: 2 per level + 2, at
+    // most 12 (24 KiB: six workgroups per CU), is ample -- measured on the 10 007-sphere scene: no
+    // difference between 10 and 20 entries, 8 costs 15 %.  A ray that does run out gives up the
+    // tree and is finished by the wave-wide scan.
+    h->bvh.depth = std::min(std::min(2 * d.depth + 2, 3 * d.depth), 12u);
     // A wave-wide scan of n spheres costs about as much as n / 80 divergent box visits.
     h->bvh_default_budget = n / 80 > 64 ? n / 80 : 64;
     h->bvh.budget = h->bvh_default_budget;
+    h->bvh.node_steps = 2;   // measured on the 10 007-sphere scene: 1: 70.5, 2: 68.8, 3: 70.6, 4: 74.4 ms per 8 iterations
+    h->bvh_default_stack = h->bvh.depth;
     for (int a = 0; a < 3; ++a) h->bvh.centre[a] = d.centre[a];
     h->bvh.half_diag = d.half_diag;
     h->bvh.r_min = d.r_min;
@@ -471,14 +480,14 @@ int pt_debug_build_bvh(const pt_sphere *spheres, uint32_t n_spheres, uint32_t co
     }
     BvhData d;
     const bool built = build_bvh(sph.data(), radius.data(), n_spheres, &d);
-    const bool fill = built && counts[0] == d.nodes.size() / 4 && counts[1] == d.leaf_index.size() / kBvhLeafSize &&
+    const bool fill = built && counts[0] == d.nodes.size() / kBvhNodeVec4 && counts[1] == d.leaf_index.size() / kBvhLeafSize &&
                       counts[2] == d.big_index.size();
     if (fill) {
         if (nodes) memcpy(nodes, d.nodes.data(), d.nodes.size() * sizeof(float4));
         if (leaf_index) memcpy(leaf_index, d.leaf_index.data(), d.leaf_index.size() * sizeof(int));
         if (big_index && !d.big_index.empty()) memcpy(big_index, d.big_index.data(), d.big_index.size() * sizeof(int));
     }
-    counts[0] = built ? (uint32_t)(d.nodes.size() / 4) : 0;
+    counts[0] = built ? (uint32_t)(d.nodes.size() / kBvhNodeVec4) : 0;
     counts[1] = built ? (uint32_t)(d.leaf_index.size() / kBvhLeafSize) : 0;
     counts[2] = built ? (uint32_t)d.big_index.size() : 0;
     counts[3] = built ? d.depth : 0;
@@ -513,6 +522,7 @@ int pt_lane_stats(pt_handle h, uint64_t out[64])
     unsigned long long v[64];
     PT_HIP(h, read_lane_stats(v));
     PT_HIP(h, add_lane_stats_wavefront(v));
+    PT_HIP(h, add_lane_stats_nee(v));
     for (int i = 0; i < 64; ++i) out[i] = (uint64_t)v[i];
     return PT_OK;
 }
@@ -554,6 +564,14 @@ int pt_debug_set_tuning(pt_handle h, int key, int value)
     case PT_TUNE_ITERATION_RANGES:
         if (value < 0 || value > 32) break;
         h->chunks = value;
+        return PT_OK;
+    case PT_TUNE_BVH_NODE_STEPS:
+        if (value < 1 || value > 16) break;
+        h->bvh.node_steps = (uint32_t)value;
+        return PT_OK;
+    case PT_TUNE_BVH_STACK:
+        if (value < 0 || value > 64) break;
+        if (h->bvh.n_nodes) h->bvh.depth = value ? (uint32_t)value : h->bvh_default_stack;
         return PT_OK;
     case PT_TUNE_WAVEFRONT_REFILL:
         if (value < 0 || value > 64) break;

@@ -28,14 +28,19 @@ struct Item {
     int index;   // original sphere index
 };
 
+// A subtree of the binary surface-area tree, before every other level is folded away.
 struct Subtree {
-    int ref;          // >= 0 inner node, < 0 ~leaf
+    int ref;          // >= 0 index into Builder::binary, < 0 ~leaf
     float lo[3], hi[3];
-    uint32_t depth;   // inner levels below and including this one
+};
+
+struct BinaryNode {
+    Subtree child[2];
 };
 
 struct Builder {
     std::vector<Item> items;
+    std::vector<BinaryNode> binary;
     const float4 *sph;
     BvhData *out;
 
@@ -134,25 +139,67 @@ struct Builder {
                 }
             }
             me.ref = ~leaf;
-            me.depth = 0;
             return me;
         }
-        const int node = (int)(out->nodes.size() / 4);
-        out->nodes.resize(out->nodes.size() + 4);
+        const int node = (int)binary.size();
+        binary.emplace_back();
         const size_t mid = choose_split(lo, hi, cmin, cmax);
         const Subtree c0 = build(lo, mid);
         const Subtree c1 = build(mid, hi);
-        float r0, r1;
-        memcpy(&r0, &c0.ref, 4);
-        memcpy(&r1, &c1.ref, 4);
-        float4 *n = &out->nodes[(size_t)node * 4];
-        n[0] = make_float4(c0.lo[0], c0.lo[1], c0.lo[2], c0.hi[0]);
-        n[1] = make_float4(c0.hi[1], c0.hi[2], c1.lo[0], c1.lo[1]);
-        n[2] = make_float4(c1.lo[2], c1.hi[0], c1.hi[1], c1.hi[2]);
-        n[3] = make_float4(r0, r1, 0.f, 0.f);
+        binary[(size_t)node].child[0] = c0;
+        binary[(size_t)node].child[1] = c1;
         me.ref = node;
-        me.depth = 1 + std::max(c0.depth, c1.depth);
         return me;
+    }
+
+    // Folds the binary tree into the four-wide one: the children of a wide node are the binary
+    // node's two children, with the inner child of the largest surface area replaced by its own
+    // two children until four are reached (or only leaves are left).  Returns the number of wide
+    // levels below and including this node.
+    uint32_t emit_wide(int binary_node, int wide_node)
+    {
+        std::vector<Subtree> kids = {binary[(size_t)binary_node].child[0], binary[(size_t)binary_node].child[1]};
+        while (kids.size() < kBvhWidth) {
+            int pick = -1;
+            float pick_area = -1.f;
+            for (size_t k = 0; k < kids.size(); ++k)
+                if (kids[k].ref >= 0 && half_area(kids[k].lo, kids[k].hi) > pick_area) {
+                    pick = (int)k;
+                    pick_area = half_area(kids[k].lo, kids[k].hi);
+                }
+            if (pick < 0) break;
+            const BinaryNode opened = binary[(size_t)kids[(size_t)pick].ref];
+            kids[(size_t)pick] = opened.child[0];
+            kids.insert(kids.begin() + pick + 1, opened.child[1]);
+        }
+        // reserve the wide nodes of the inner children first: a node's index must be known before its subtree is emitted
+        int refs[kBvhWidth];
+        for (size_t k = 0; k < kBvhWidth; ++k) {
+            refs[k] = kBvhNoChild;
+            if (k < kids.size()) {
+                refs[k] = kids[k].ref;
+                if (kids[k].ref >= 0) {
+                    refs[k] = (int)(out->nodes.size() / kBvhNodeVec4);
+                    out->nodes.resize(out->nodes.size() + kBvhNodeVec4);
+                }
+            }
+        }
+        float v[kBvhNodeVec4][4];
+        for (size_t k = 0; k < kBvhWidth; ++k) {
+            const bool used = k < kids.size();
+            for (int a = 0; a < 3; ++a) {
+                v[a][k] = used ? kids[k].lo[a] : NAN;
+                v[3 + a][k] = used ? kids[k].hi[a] : NAN;
+            }
+            memcpy(&v[6][k], &refs[k], 4);
+            v[7][k] = 0.f;
+        }
+        for (size_t q = 0; q < kBvhNodeVec4; ++q)
+            out->nodes[(size_t)wide_node * kBvhNodeVec4 + q] = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+        uint32_t below = 0;
+        for (size_t k = 0; k < kids.size(); ++k)
+            if (kids[k].ref >= 0) below = std::max(below, emit_wide(kids[k].ref, refs[k]));
+        return 1 + below;
     }
 };
 
@@ -216,9 +263,10 @@ bool build_bvh(const float4 *sph, const float *radius, uint32_t n, BvhData *out)
         b.items.push_back(it);
         out->r_min = std::min(out->r_min, radius[i]);
     }
-    const Subtree root = b.build(0, b.items.size());   // more than one leaf: the root is inner node 0
-    out->depth = root.depth;
-    return root.depth <= kBvhMaxDepth;
+    const Subtree root = b.build(0, b.items.size());   // more than one leaf: the root is an inner node
+    out->nodes.resize(kBvhNodeVec4);                   // wide node 0
+    out->depth = b.emit_wide(root.ref, 0);
+    return out->depth <= kBvhMaxDepth;
 }
 
 } // namespace ptmi

@@ -11,11 +11,18 @@ constexpr uint32_t kBvhLeafSize = 4;     // sphere slots per leaf
 constexpr uint32_t kBvhMaxBig = 64;      // always-tested spheres kept beside the tree
 constexpr uint32_t kBvhMaxDepth = 28;    // inner levels == entries of the per-lane traversal stack
 
+constexpr uint32_t kBvhWidth = 4;        // children per inner node
+constexpr int kBvhNoChild = 0x7fffffff;  // reference of an unused child slot
+constexpr uint32_t kBvhNodeVec4 = 8;     // float4 per inner node (128 bytes: one cache line)
+
 struct BvhData {
-    // Binary tree, four float4 per inner node holding the boxes of BOTH children:
-    //   [0] = (lo0.x, lo0.y, lo0.z, hi0.x)   [1] = (hi0.y, hi0.z, lo1.x, lo1.y)
-    //   [2] = (lo1.z, hi1.x, hi1.y, hi1.z)   [3] = bits (child0, child1, 0, 0)
-    // A child reference >= 0 is an inner node index, < 0 is ~leaf.  Node 0 is the root.
+    // Four-wide tree.  An inner node is eight float4 (one 128-byte line), the boxes of its up to
+    // four children in structure-of-arrays order:
+    //   [0] lo.x of children 0..3   [1] lo.y   [2] lo.z   [3] hi.x   [4] hi.y   [5] hi.z
+    //   [6] bits: the four child references   [7] unused
+    // A child reference >= 0 is an inner node index, < 0 is ~leaf, kBvhNoChild marks an unused slot
+    // (its box is all NaN).  Node 0 is the root.  The tree is the binary surface-area tree with
+    // every other level folded into its parent: half as many dependent node fetches per ray.
     std::vector<float4> nodes;
     std::vector<float4> leaf_sph;  // [leaf][kBvhLeafSize] spheres (cx, cy, cz, r*r); unused slots can never be hit
     std::vector<int> leaf_index;   // [leaf][kBvhLeafSize] their original indices

@@ -62,7 +62,7 @@ hipError_t static_steal_scratch(int device, StealScratch *out);
 
 // Sphere BVH in device memory (layout: pt_bvh.hpp); n_nodes == 0 when there is none.
 struct BvhParams {
-    const float4 *nodes;      // four float4 per inner node, node 0 is the root
+    const float4 *nodes;      // eight float4 per four-wide inner node, node 0 is the root
     const float4 *leaf_sph;   // [leaf][4]
     const int4 *leaf_index;   // [leaf]
     const float4 *big_sph;
@@ -70,6 +70,7 @@ struct BvhParams {
     uint32_t n_nodes, n_big;
     uint32_t depth;           // entries of the per-lane traversal stack
     uint32_t budget;          // box/leaf visits after which a ray is finished by a wave-wide scan
+    uint32_t node_steps;      // inner-node steps a wave takes per leaf step (the lanes of a wave alternate in lockstep)
     float centre[3];
     float half_diag, r_min;
     unsigned long long *stats;   // 32 counters, written only by -DPT_BVH_STATS builds
@@ -131,6 +132,7 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid_x, uint32_t grid_y
 
 hipError_t read_lane_stats(unsigned long long out[64]);
 hipError_t add_lane_stats_wavefront(unsigned long long out[64]);
+hipError_t add_lane_stats_nee(unsigned long long out[64]);
 
 hipError_t launch_render_steal(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled, bool nee,
                                bool record, hipStream_t stream);

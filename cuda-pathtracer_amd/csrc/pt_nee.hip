@@ -132,6 +132,23 @@ __global__ __launch_bounds__(kBlockThreads) void render_nee_kernel(const RenderP
 
 } // namespace
 
+// Divergence counters of the kernel in this file (measurement builds only; every translation unit
+// has its own copy of the counter array), added to out[64] and cleared.
+hipError_t add_lane_stats_nee(unsigned long long out[64])
+{
+#ifdef PT_LANE_STATS
+    unsigned long long v[64];
+    hipError_t e = hipMemcpyFromSymbol(v, HIP_SYMBOL(g_lane_stats), sizeof v);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < 64; ++i) out[i] += v[i];
+    static const unsigned long long zeros[64] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stats), zeros, sizeof zeros);
+#else
+    (void)out;
+    return hipSuccess;
+#endif
+}
+
 hipError_t launch_render_nee(const RenderParams &p, uint32_t grid_x, uint32_t grid_y, bool tiled, bool record,
                              hipStream_t stream)
 {

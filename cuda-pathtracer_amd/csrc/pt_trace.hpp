@@ -173,10 +173,12 @@ struct BvhMargin {
     float err;     // 1e-6 * L^2 * |dir|^2: rounding error of the sphere test's discriminant
     float slack;   // rounding of the slab arithmetic
     float r_min;
+    // sqrt(r_min^2 + E2) - r_min, rounded up: hardware square root and reciprocal (1 ulp each) with
+    // a factor that covers their errors -- this arithmetic only decides which boxes are visited
     PT_DEV float at(float T) const
     {
         const float E2 = eps * T * T + err;
-        return E2 / (__builtin_sqrtf(r_min * r_min + E2) + r_min) * 1.001f + slack;
+        return E2 * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(r_min * r_min + E2) * 0.999999f + r_min) * 1.001f + slack;
     }
 };
 
@@ -243,7 +245,7 @@ PT_DEV bool bvh_pop(const uint2 *stack, int &sp, float tmax, int &cur)
 // order -- and the wave then finishes such rays together, one at a time: 64 lanes scan the sphere
 // array in stride and reduce (t, index) across the wave.  Every lane of the wave must call this
 // function (`active` masks the lanes that carry a ray).
-constexpr int kBvhNodeStepsPerLeafStep = 3;
+
 
 struct BvhTraversal {
     BvhMargin m;
@@ -260,7 +262,7 @@ PT_DEV bool bvh_begin(const BvhParams &B, V3 o, V3 d, float &tmax, int &best, Bv
 {
     for (uint32_t i = 0; i < B.n_big; ++i) sphere_test_lex(B.big_sph[i], B.big_index[i], o, d, tmax, best);
     const float cx = o.x - B.centre[0], cy = o.y - B.centre[1], cz = o.z - B.centre[2];
-    const float L = __builtin_sqrtf(cx * cx + cy * cy + cz * cz) * 1.000001f + B.half_diag;
+    const float L = __builtin_amdgcn_sqrtf(cx * cx + cy * cy + cz * cz) * 1.000002f + B.half_diag;
     const float excess = (d.x * d.x + d.y * d.y + d.z * d.z) - 1.f;
     tr.m.eps = __builtin_fmaxf(excess, 0.f) * 1.000001f + 4e-7f;
     // b = op . dir grows with |dir|, and with it the rounding errors of b * b and of t = b -+ sqrt(det)
@@ -279,30 +281,39 @@ PT_DEV bool bvh_begin(const BvhParams &B, V3 o, V3 d, float &tmax, int &best, Bv
     return !(excess != excess || L != L);
 }
 
-// One inner node (tr.cur >= 0): tests both children, descends into the nearer one.  Returns false
-// when the traversal is finished (stack empty).
+// One inner node (tr.cur >= 0) of the four-wide tree: tests its up to four child boxes, descends
+// into the nearest one that is hit and defers the others on the stack (in slot order: the order of
+// visits affects only how early the bound tightens, never the result).  Returns false when the
+// traversal is finished (stack empty).  A full stack makes the ray give up the tree: its visit
+// count is set beyond any budget, so that the caller finishes it by the wave-wide scan.
 PT_DEV bool bvh_node_step(const BvhParams &B, uint2 *stack, V3 o, float tmax, BvhTraversal &tr)
 {
     PT_LS(23);
-    const float4 *N = B.nodes + 4 * (size_t)tr.cur;
-    const float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
-    float tn0, tn1;
-    const bool hit0 = bvh_box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tr.ray, o, tr.e, tr.refine, tr.m, tmax, tn0);
-    const bool hit1 = bvh_box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tr.ray, o, tr.e, tr.refine, tr.m, tmax, tn1);
-    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+    const float4 *N = B.nodes + 8 * (size_t)tr.cur;
+    const float4 lx = N[0], ly = N[1], lz = N[2], hx = N[3], hy = N[4], hz = N[5], rf = N[6];
+    const int c0 = __float_as_int(rf.x), c1 = __float_as_int(rf.y), c2 = __float_as_int(rf.z), c3 = __float_as_int(rf.w);
+    float t0, t1, t2, t3;
+    const bool h0 = bvh_box_test(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, tr.ray, o, tr.e, tr.refine, tr.m, tmax, t0);   // slots 0 and 1 are always used
+    const bool h1 = bvh_box_test(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, tr.ray, o, tr.e, tr.refine, tr.m, tmax, t1);
+    const bool h2 = c2 != 0x7fffffff && bvh_box_test(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, tr.ray, o, tr.e, tr.refine, tr.m, tmax, t2);
+    const bool h3 = c3 != 0x7fffffff && bvh_box_test(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, tr.ray, o, tr.e, tr.refine, tr.m, tmax, t3);
     ++tr.visits;
-    if (hit0 && hit1) {
-        const bool first0 = tn0 <= tn1;
-        stack[tr.sp * kBlockThreads] = make_uint2((uint32_t)(first0 ? c1 : c0), __float_as_uint(first0 ? tn1 : tn0));
-        ++tr.sp;
-        tr.cur = first0 ? c0 : c1;
-        return true;
-    }
-    if (hit0 || hit1) {
-        tr.cur = hit0 ? c0 : c1;
-        return true;
-    }
-    return bvh_pop(stack, tr.sp, tmax, tr.cur);
+    // nearest hit child (NaN entry distances lose against everything, which is fine: they are only a visiting order)
+    int near_slot = -1;
+    float near_t = PT_INF;
+    if (h0) { near_slot = 0; near_t = t0; }
+    if (h1 && (near_slot < 0 || t1 < near_t)) { near_slot = 1; near_t = t1; }
+    if (h2 && (near_slot < 0 || t2 < near_t)) { near_slot = 2; near_t = t2; }
+    if (h3 && (near_slot < 0 || t3 < near_t)) { near_slot = 3; near_t = t3; }
+    if (near_slot < 0) return bvh_pop(stack, tr.sp, tmax, tr.cur);
+    const int n_defer = (int)h0 + (int)h1 + (int)h2 + (int)h3 - 1;
+    if (tr.sp + n_defer > (int)B.depth) { tr.visits = 0xffffffffu; return true; }
+    if (h0 && near_slot != 0) { stack[tr.sp * kBlockThreads] = make_uint2((uint32_t)c0, __float_as_uint(t0)); ++tr.sp; }
+    if (h1 && near_slot != 1) { stack[tr.sp * kBlockThreads] = make_uint2((uint32_t)c1, __float_as_uint(t1)); ++tr.sp; }
+    if (h2 && near_slot != 2) { stack[tr.sp * kBlockThreads] = make_uint2((uint32_t)c2, __float_as_uint(t2)); ++tr.sp; }
+    if (h3 && near_slot != 3) { stack[tr.sp * kBlockThreads] = make_uint2((uint32_t)c3, __float_as_uint(t3)); ++tr.sp; }
+    tr.cur = near_slot == 0 ? c0 : (near_slot == 1 ? c1 : (near_slot == 2 ? c2 : c3));
+    return true;
 }
 
 // One leaf (tr.cur < 0): its four sphere slots, then the next deferred box.
@@ -366,7 +377,7 @@ PT_DEV void intersect_bvh(const BvhParams &B, const float4 *sph, uint32_t n_prim
 #endif
     while (more) {
 #pragma unroll 1
-        for (int k = 0; k < kBvhNodeStepsPerLeafStep; ++k) {
+        for (uint32_t k = 0; k < B.node_steps; ++k) {
             if (more && tr.cur >= 0) {
                 PT_BVH_COUNT(st_nodes);
                 PT_BVH_WAVE_COUNT(st_wave_nodes);

@@ -160,8 +160,10 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
 // state in registers and their stacks in LDS.  Results do not depend on which lane traces which
 // path; only the order of the survivors in the next queue changes.
 
-template <int NODE_STEPS>
-__global__ __launch_bounds__(kBlockThreads) void wf_step_bvh_kernel(const WavefrontParams p)
+#ifndef PT_WF_BVH_WAVES
+#define PT_WF_BVH_WAVES 6
+#endif
+__global__ __launch_bounds__(kBlockThreads, PT_WF_BVH_WAVES) void wf_step_bvh_kernel(const WavefrontParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int tid = threadIdx.x;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_bvh_kernel(const Wavefr
             // A fixed number of box steps per leaf step: waiting until no lane of the wave is at an
             // inner node any more (the classic while-while) measured 25 % slower, one step 8 %.
 #pragma unroll 1
-            for (int k = 0; k < NODE_STEPS; ++k) {
+            for (uint32_t k = 0; k < B.node_steps; ++k) {
                 if (trav && tr.cur >= 0) {
                     trav = bvh_node_step(B, stack, o, tmax, tr);
                     if (tr.visits > B.budget) { over = trav; trav = false; }
@@ -382,7 +384,7 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
         if (per_cu < 1u) per_cu = 1u;
         uint32_t rows = (per_cu * (uint32_t)n_cus + kWfSubQueues - 1) / kWfSubQueues;
         const dim3 pgrid(kWfSubQueues, chunks < rows ? chunks : rows);
-        hipLaunchKernelGGL((wf_step_bvh_kernel<kBvhNodeStepsPerLeafStep>), pgrid, block, lds, stream, p);
+        hipLaunchKernelGGL(wf_step_bvh_kernel, pgrid, block, lds, stream, p);
     } else if (bvh) hipLaunchKernelGGL((wf_step_kernel<true, true>), grid, block, lds, stream, p);
     else if (tiled) hipLaunchKernelGGL((wf_step_kernel<true, false>), grid, block, lds, stream, p);
     else            hipLaunchKernelGGL((wf_step_kernel<false, false>), grid, block, lds, stream, p);

@@ -187,9 +187,14 @@ int pt_set_kernel_variant(pt_handle h, int variant);
  *                              change hands
  *   PT_TUNE_ITERATION_RANGES   0: chosen per launch; n: a launch is cut into n iteration ranges
  *   PT_TUNE_WAVEFRONT_REFILL   BVH scenes: lanes still traversing below which a persistent wave
- *                              refills (default 32); 0: static assignment of paths to lanes */
+ *                              refills (default 32); 0: static assignment of paths to lanes
+ *   PT_TUNE_BVH_NODE_STEPS     1..16: inner-node steps per leaf step of the BVH traversal (default 2;
+ *                              reset by pt_init_scene, not by pt_set_kernel_variant)
+ *   PT_TUNE_BVH_STACK          entries of the per-lane traversal stack (0: the default, two per
+ *                              tree level + 2; a ray that runs out is finished by the wave-wide
+ *                              scan; reset by pt_init_scene) */
 enum { PT_TUNE_REGEN_MIN_IDLE = 0, PT_TUNE_CAMERA_RAY_RING = 1, PT_TUNE_STEAL_UNIT = 2, PT_TUNE_ITERATION_RANGES = 3,
-       PT_TUNE_WAVEFRONT_REFILL = 4 };
+       PT_TUNE_WAVEFRONT_REFILL = 4, PT_TUNE_BVH_NODE_STEPS = 5, PT_TUNE_BVH_STACK = 6 };
 int pt_debug_set_tuning(pt_handle h, int key, int value);
 /* Device memory held by the instance: bytes[0] = allocated now (scene, BVH, scratch pool,
  * tickets, wavefront queues, internal frame buffer); bytes[1] = what a pt_run_n of n_iterations
@@ -231,9 +236,11 @@ int pt_set_accel_budget(pt_handle h, uint32_t visits);
 /* Test hook, host only (no device needed): builds the BVH pt_init_scene would build for these
  * spheres, whatever their number.  counts = {inner nodes, leaves, always-tested spheres, depth}
  * on return, all 0 when no hierarchy is built.  The arrays (may be NULL) are filled only when
- * counts holds the first three values on entry: nodes [inner nodes][16] floats (two child boxes
- * and two child references as laid out in device memory), leaf_index [leaves][4] sphere indices
- * (0x7fffffff = empty slot), big_index [always-tested].  Call once to size, once to fill. */
+ * counts holds the first three values on entry: nodes [inner nodes][32] floats (a four-wide node
+ * as laid out in device memory: lo.x, lo.y, lo.z, hi.x, hi.y, hi.z of the four children, their
+ * four references as int bits -- >= 0 inner node, < 0 ~leaf, 0x7fffffff unused slot -- and four
+ * unused floats), leaf_index [leaves][4] sphere indices (0x7fffffff = empty slot), big_index
+ * [always-tested].  Call once to size, once to fill. */
 int pt_debug_build_bvh(const pt_sphere *spheres, uint32_t n_spheres, uint32_t counts[4], float *nodes,
                        int32_t *leaf_index, int32_t *big_index);
 /* Traversal counters since the last call (only libraries built with -DPT_BVH_STATS count -- the

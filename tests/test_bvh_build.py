@@ -19,19 +19,25 @@ def check(pt, sph):
     if b is None:
         return None
     nodes, leaf, big = b["nodes"], b["leaf_index"], b["big_index"]
-    refs = nodes[:, 12:14].copy().view(np.int32)
+    NONE = 0x7fffffff
+    refs = nodes[:, 24:28].copy().view(np.int32)                  # [node][child]
+    used_slot = refs != NONE
+    # slots 0 and 1 are always used (the traversal tests them unconditionally); unused slots hold NaN boxes
+    assert used_slot[:, :2].all()
     # every sphere is in exactly one leaf slot or in the always-tested list
-    used = leaf[leaf != 0x7fffffff]
+    used = leaf[leaf != NONE]
     everything = np.sort(np.concatenate([used, big]))
     assert np.array_equal(everything, np.arange(len(sph)))
     # every inner node except the root and every leaf is referenced exactly once
-    inner_refs = np.sort(refs[refs >= 0])
+    live = refs[used_slot]
+    inner_refs = np.sort(live[live >= 0])
     assert np.array_equal(inner_refs, np.arange(1, len(nodes)))
-    leaf_refs = np.sort(~refs[refs < 0])
+    leaf_refs = np.sort(~live[live < 0])
     assert np.array_equal(leaf_refs, np.arange(len(leaf)))
-    # child boxes contain the spheres below them; depth is what the stack is sized for
-    lo = np.stack([nodes[:, 0:3], nodes[:, 6:9]], 1)              # [node][child][xyz]
-    hi = np.stack([np.column_stack([nodes[:, 3], nodes[:, 4], nodes[:, 5]]), nodes[:, 9:12]], 1)
+    # child boxes contain the spheres below them; depth is what the stack is sized from
+    lo = nodes[:, 0:12].reshape(-1, 3, 4).transpose(0, 2, 1)      # [node][child][xyz]
+    hi = nodes[:, 12:24].reshape(-1, 3, 4).transpose(0, 2, 1)
+    assert np.isnan(lo[~used_slot]).all() and np.isnan(hi[~used_slot]).all()
 
     bounded = np.setdiff1d(np.arange(len(sph)), big)
     extent = float(np.abs(sph["pos"][bounded]).max() + np.abs(sph["radius"][bounded]).max())
@@ -39,19 +45,21 @@ def check(pt, sph):
     def walk(ref, depth):
         if ref < 0:
             idx = leaf[~ref]
-            idx = idx[idx != 0x7fffffff]
+            idx = idx[idx != NONE]
             c, r = sph["pos"][idx].astype(np.float64), np.abs(sph["radius"][idx].astype(np.float64))
             return (c - r[:, None]).min(0), (c + r[:, None]).max(0), 0
         d = 0
         mins, maxs = [], []
-        for k in (0, 1):
+        for k in range(4):
+            if refs[ref, k] == NONE:
+                continue
             cl, ch, cd = walk(int(refs[ref, k]), depth + 1)
             assert (lo[ref, k] <= cl).all() and (hi[ref, k] >= ch).all(), (ref, k)
             # ... and not by much: slack is 1e-4 + 1e-6 of the cloud's size
             tol = 0.01 + 1e-5 * extent
             assert (cl - lo[ref, k]).max() < tol and (hi[ref, k] - ch).max() < tol
             mins.append(cl); maxs.append(ch); d = max(d, cd)
-        return np.minimum(*mins), np.maximum(*maxs), d + 1
+        return np.min(mins, axis=0), np.max(maxs, axis=0), d + 1
 
     _, _, depth = walk(0, 0)
     assert depth == b["depth"] <= 28
@@ -66,8 +74,15 @@ def test_invariants_on_random_scenes(pt):
         assert b is not None and len(b["big_index"]) == 6
         # cuts leave multiples of the leaf size on the left: leaves are full
         assert len(b["leaf_index"]) == -(-n // 4)
-        # both sides of a cut hold between 3/8 and 5/8 of the range
-        assert b["depth"] <= np.ceil(np.log(max(n / 4, 1)) / np.log(8 / 5)) + 1
+        # both sides of a binary cut hold between 3/8 and 5/8 of the range, and a four-wide node
+        # folds at least ... one binary level: the wide depth is bounded by the binary bound,
+        # and is about half of it
+        binary_bound = np.ceil(np.log(max(n / 4, 1)) / np.log(8 / 5)) + 1
+        assert b["depth"] <= binary_bound
+        assert b["depth"] <= np.ceil(np.log2(max(n / 4, 2))) * 0.75 + 1
+        # most child slots are in use
+        refs = b["nodes"][:, 24:28].copy().view(np.int32)
+        assert (refs != 0x7fffffff).mean() > 0.7
 
 
 def test_degenerate_inputs(pt):

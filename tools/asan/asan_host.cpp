@@ -90,16 +90,19 @@ static void check_bvh(const std::vector<float4> &sph, const std::vector<float> &
     for (int i : d.leaf_index) if (i != 0x7fffffff) { CHECK(i >= 0 && (uint32_t)i < n); if (i >= 0 && (uint32_t)i < n) ++seen[i]; }
     for (int i : d.big_index) { CHECK(i >= 0 && (uint32_t)i < n); if (i >= 0 && (uint32_t)i < n) ++seen[i]; }
     for (uint32_t i = 0; i < n; ++i) CHECK(seen[i] == 1);
-    CHECK(d.nodes.size() % 4 == 0 && d.leaf_sph.size() == d.leaf_index.size());
+    CHECK(d.nodes.size() % ptmi::kBvhNodeVec4 == 0 && d.leaf_sph.size() == d.leaf_index.size());
     CHECK(d.depth <= ptmi::kBvhMaxDepth && d.big_index.size() <= ptmi::kBvhMaxBig);
-    const int n_nodes = (int)(d.nodes.size() / 4), n_leaves = (int)(d.leaf_index.size() / ptmi::kBvhLeafSize);
-    for (int k = 0; k < n_nodes; ++k)
-        for (int c = 0; c < 2; ++c) {
+    const int n_nodes = (int)(d.nodes.size() / ptmi::kBvhNodeVec4), n_leaves = (int)(d.leaf_index.size() / ptmi::kBvhLeafSize);
+    for (int k = 0; k < n_nodes; ++k) {
+        const float4 r = d.nodes[(size_t)ptmi::kBvhNodeVec4 * k + 6];
+        const float f[4] = {r.x, r.y, r.z, r.w};
+        for (int c = 0; c < 4; ++c) {
             int ref;
-            const float f = c ? d.nodes[4 * k + 3].y : d.nodes[4 * k + 3].x;
-            memcpy(&ref, &f, 4);
+            memcpy(&ref, &f[c], 4);
+            if (ref == ptmi::kBvhNoChild) { CHECK(c >= 2); continue; }
             CHECK(ref >= 0 ? ref < n_nodes : ~ref < n_leaves);
         }
+    }
 }
 
 static void bvhs()
