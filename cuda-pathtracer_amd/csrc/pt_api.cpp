@@ -233,14 +233,14 @@ static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sp
     auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
     const size_t n_nodes = d.nodes.size() / kBvhNodeVec4, n_slots = d.leaf_sph.size(), n_big = d.big_sph.size();
     const size_t off_nodes = 0;
-    const size_t off_ls = off_nodes + pad(d.nodes.size() * sizeof(float4));
+    const size_t off_ls = off_nodes + pad(d.qnodes.size() * sizeof(uint4));
     const size_t off_li = off_ls + pad(n_slots * sizeof(float4));
     const size_t off_bs = off_li + pad(n_slots * sizeof(int));
     const size_t off_bi = off_bs + pad((n_big ? n_big : 1) * sizeof(float4));
     const size_t off_st = off_bi + pad((n_big ? n_big : 1) * sizeof(int));
     const size_t total = off_st + 256;
     std::vector<unsigned char> blob(total, 0);
-    memcpy(&blob[off_nodes], d.nodes.data(), d.nodes.size() * sizeof(float4));
+    memcpy(&blob[off_nodes], d.qnodes.data(), d.qnodes.size() * sizeof(uint4));
     memcpy(&blob[off_ls], d.leaf_sph.data(), n_slots * sizeof(float4));
     memcpy(&blob[off_li], d.leaf_index.data(), n_slots * sizeof(int));
     if (n_big) {
@@ -251,7 +251,7 @@ static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sp
     PT_HIP(h, hipMemcpy(h->d_bvh, blob.data(), total, hipMemcpyHostToDevice));
     h->scene_bytes += total;
     const unsigned char *base = (const unsigned char *)h->d_bvh;
-    h->bvh.nodes = (const float4 *)(base + off_nodes);
+    h->bvh.nodes = (const uint4 *)(base + off_nodes);
     h->bvh.leaf_sph = (const float4 *)(base + off_ls);
     h->bvh.leaf_index = (const int4 *)(base + off_li);
     h->bvh.big_sph = (const float4 *)(base + off_bs);
@@ -259,6 +259,7 @@ static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sp
     h->bvh.stats = (unsigned long long *)((unsigned char *)h->d_bvh + off_st);
     h->bvh.n_nodes = (uint32_t)n_nodes;
     h->bvh.n_big = (uint32_t)n_big;
+    h->bvh.n_leaves = (uint32_t)(n_slots / kBvhLeafSize);
     // Entries of the per-lane traversal stack (LDS, 2 KiB per entry and workgroup).  A node defers up
     // to three children, but a ray rarely meets more than two of four boxes: 2 per level + 2, at
     // most 12 (24 KiB: six workgroups per CU), is ample -- measured on the 10 007-sphere scene: no
@@ -270,7 +271,7 @@ static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sp
     h->bvh.budget = h->bvh_default_budget;
     h->bvh.node_steps = 2;   // measured on the 10 007-sphere scene: 1: 70.5, 2: 68.8, 3: 70.6, 4: 74.4 ms per 8 iterations
     h->bvh_default_stack = h->bvh.depth;
-    for (int a = 0; a < 3; ++a) h->bvh.centre[a] = d.centre[a];
+    for (int a = 0; a < 3; ++a) { h->bvh.centre[a] = d.centre[a]; h->bvh.grid_origin[a] = d.grid_origin[a]; h->bvh.grid_step[a] = d.grid_step[a]; h->bvh.grid_inv_step[a] = 1.f / d.grid_step[a]; }
     h->bvh.half_diag = d.half_diag;
     h->bvh.r_min = d.r_min;
     return PT_OK;

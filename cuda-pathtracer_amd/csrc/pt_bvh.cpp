@@ -205,9 +205,51 @@ struct Builder {
 
 } // namespace
 
+// The 16-bit grid form of the nodes (layout: pt_bvh.hpp).  lo / hi: extent of the bounded spheres.
+static void quantize_nodes(BvhData *out, const float lo[3], const float hi[3])
+{
+    const size_t n_nodes = out->nodes.size() / kBvhNodeVec4;
+    double origin[3], step[3];
+    for (int a = 0; a < 3; ++a) {
+        // the node boxes exceed the spheres' extent by their slack: leave a margin of 1/64 of the
+        // extent (and at least a little) on both sides, and four grid steps for the outward rounding
+        const double extent = std::max((double)hi[a] - (double)lo[a], 1e-3);
+        const double margin = extent / 64 + 1e-3;
+        step[a] = (extent + 2 * margin) / 65520.0;
+        out->grid_step[a] = (float)step[a];
+        step[a] = (double)out->grid_step[a];                      // the step the device uses
+        out->grid_origin[a] = (float)((double)lo[a] - margin - 4 * step[a]);
+        origin[a] = (double)out->grid_origin[a];
+    }
+    out->qnodes.assign(n_nodes * 4, make_uint4(0u, 0u, 0u, 0u));
+    for (size_t k = 0; k < n_nodes; ++k) {
+        const float4 *N = &out->nodes[k * kBvhNodeVec4];
+        uint32_t q[6][4];
+        for (int plane = 0; plane < 6; ++plane) {
+            const float v[4] = {N[plane].x, N[plane].y, N[plane].z, N[plane].w};
+            const int a = plane % 3;
+            for (int c = 0; c < 4; ++c) {
+                double g = ((double)v[c] - origin[a]) / step[a];
+                g = plane < 3 ? std::floor(g) - 2 : std::ceil(g) + 2;
+                if (!(g >= 0)) g = 0;                              // NaN (unused slot) as well
+                if (g > 65535) g = 65535;
+                q[plane][c] = (uint32_t)g;
+            }
+        }
+        auto pack = [&q](int plane, int pair) { return q[plane][2 * pair] | (q[plane][2 * pair + 1] << 16); };
+        uint4 *Q = &out->qnodes[k * 4];
+        Q[0] = make_uint4(pack(0, 0), pack(0, 1), pack(1, 0), pack(1, 1));
+        Q[1] = make_uint4(pack(2, 0), pack(2, 1), pack(3, 0), pack(3, 1));
+        Q[2] = make_uint4(pack(4, 0), pack(4, 1), pack(5, 0), pack(5, 1));
+        uint32_t r[4];
+        memcpy(r, &N[6], 16);
+        Q[3] = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+}
+
 bool build_bvh(const float4 *sph, const float *radius, uint32_t n, BvhData *out)
 {
-    out->nodes.clear(); out->leaf_sph.clear(); out->leaf_index.clear();
+    out->nodes.clear(); out->qnodes.clear(); out->leaf_sph.clear(); out->leaf_index.clear();
     out->big_sph.clear(); out->big_index.clear();
     out->depth = 0;
     if (n == 0) return false;
@@ -266,6 +308,7 @@ bool build_bvh(const float4 *sph, const float *radius, uint32_t n, BvhData *out)
     const Subtree root = b.build(0, b.items.size());   // more than one leaf: the root is an inner node
     out->nodes.resize(kBvhNodeVec4);                   // wide node 0
     out->depth = b.emit_wide(root.ref, 0);
+    quantize_nodes(out, lo, hi);
     return out->depth <= kBvhMaxDepth;
 }
 

@@ -24,6 +24,16 @@ struct BvhData {
     // (its box is all NaN).  Node 0 is the root.  The tree is the binary surface-area tree with
     // every other level folded into its parent: half as many dependent node fetches per ray.
     std::vector<float4> nodes;
+    // The same nodes as the traversal reads them: four uint4 (64 bytes) per node, every box plane a
+    // 16-bit coordinate on a grid over the bounded spheres' extent (plane = grid_origin +
+    // q * grid_step per axis), lower planes rounded down and upper planes up, two more steps
+    // outwards to cover the rounding of the traversal's plane arithmetic:
+    //   [0] lo.x of children 0..3 (two per word, child 0 in the low half), lo.y likewise
+    //   [1] lo.z, hi.x   [2] hi.y, hi.z   [3] the four child references
+    // Halves the bytes and nearly halves the load instructions per node visit, which is what the
+    // traversal is bound by (measured: three extra loads per visit cost 19 %).
+    std::vector<uint4> qnodes;
+    float grid_origin[3], grid_step[3];
     std::vector<float4> leaf_sph;  // [leaf][kBvhLeafSize] spheres (cx, cy, cz, r*r); unused slots can never be hit
     std::vector<int> leaf_index;   // [leaf][kBvhLeafSize] their original indices
     std::vector<float4> big_sph;   // always-tested spheres

@@ -62,17 +62,18 @@ hipError_t static_steal_scratch(int device, StealScratch *out);
 
 // Sphere BVH in device memory (layout: pt_bvh.hpp); n_nodes == 0 when there is none.
 struct BvhParams {
-    const float4 *nodes;      // eight float4 per four-wide inner node, node 0 is the root
+    const uint4 *nodes;       // four uint4 per four-wide inner node (16-bit grid planes + child references), node 0 is the root
     const float4 *leaf_sph;   // [leaf][4]
     const int4 *leaf_index;   // [leaf]
     const float4 *big_sph;
     const int *big_index;
-    uint32_t n_nodes, n_big;
+    uint32_t n_nodes, n_big, n_leaves;
     uint32_t depth;           // entries of the per-lane traversal stack
     uint32_t budget;          // box/leaf visits after which a ray is finished by a wave-wide scan
     uint32_t node_steps;      // inner-node steps a wave takes per leaf step (the lanes of a wave alternate in lockstep)
     float centre[3];
     float half_diag, r_min;
+    float grid_origin[3], grid_step[3], grid_inv_step[3];   // plane = grid_origin + q * grid_step
     unsigned long long *stats;   // 32 counters, written only by -DPT_BVH_STATS builds
 };
 

@@ -160,12 +160,14 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
 // state in registers and their stacks in LDS.  Results do not depend on which lane traces which
 // path; only the order of the survivors in the next queue changes.
 
-#ifndef PT_WF_BVH_WAVES
-#define PT_WF_BVH_WAVES 6
-#endif
-__global__ __launch_bounds__(kBlockThreads, PT_WF_BVH_WAVES) void wf_step_bvh_kernel(const WavefrontParams p)
+//
+// Measured and dropped: the tree's inner nodes staged in LDS by one 1024-thread workgroup per CU
+// (4-byte stack entries, 130 KiB of LDS on the 10 007-sphere scene) -- 61.3 ms per 8 iterations
+// against 53.8 ms: four waves per SIMD instead of six cost more than the shorter fetches gain.
+__global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const WavefrontParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int BT = kBlockThreads;
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
     const uint32_t q = blockIdx.x;
@@ -181,12 +183,14 @@ __global__ __launch_bounds__(kBlockThreads, PT_WF_BVH_WAVES) void wf_step_bvh_ke
     } else {
         n_items = *count_ptr(p.counts, p.bounce, q);
     }
-    if (blockIdx.y * kBlockThreads >= n_items) return;
+    if (blockIdx.y * (uint32_t)BT >= n_items) return;
     uint32_t *cursor = count_ptr(p.counts, p.bounce, q) + 1;   // second word of the counter's line
 
     const BvhParams &B = p.scene.bvh;
     const SceneView sc = stage_scene<true>(p.scene, lds_raw, tid);
-    uint2 *stack = reinterpret_cast<uint2 *>(lds_raw) + tid;
+    BvhStack8<BT> stack;   // LDS: [stack entries][BT lanes]
+    stack.base = reinterpret_cast<uint2 *>(lds_raw) + tid;
+    const uint4 *nodes = B.nodes;
     const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
 
     bool has = false, trav = false, over = false, exhausted = false;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(kBlockThreads, PT_WF_BVH_WAVES) void wf_step_bvh_ke
 #pragma unroll 1
             for (uint32_t k = 0; k < B.node_steps; ++k) {
                 if (trav && tr.cur >= 0) {
-                    trav = bvh_node_step(B, stack, o, tmax, tr);
+                    trav = bvh_node_step(B, nodes, stack, o, tmax, tr);
                     if (tr.visits > B.budget) { over = trav; trav = false; }
                 }
             }
