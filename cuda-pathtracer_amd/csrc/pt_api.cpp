@@ -63,9 +63,18 @@ struct pt_context {
     bool wavefront;
     bool auto_variant;
     int wf_dynamic_fetch;   // BVH scenes: refill threshold of the persistent waves, 0 = static chunks
-    WavefrontQueue wf_queue[2];
-    float *wf_radiance;
-    uint32_t *wf_counts;
+    // Two sets of batch buffers: consecutive batches alternate between them and run on two streams
+    // (set 0 on the caller's stream, set 1 on wf_stream2), so that the tail of one batch's launch --
+    // the last, longest traversals -- overlaps with the other batch's launches.
+    struct WfPipe {
+        WavefrontQueue queue[2];
+        float *radiance;
+        uint32_t *counts;
+        hipEvent_t resolved;    // recorded after the set's resolve kernel
+    } wf_pipe[2];
+    hipStream_t wf_stream2;
+    hipEvent_t wf_fork;
+    uint32_t wf_target_mpaths;   // paths per wavefront batch in units of 2^20 (0: kWfTargetPaths)
     uint32_t wf_sub_capacity;   // paths per sub-queue the buffers were sized for
     uint64_t wf_capacity;       // paths per batch the buffers were sized for
     std::string error;
@@ -184,9 +193,10 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->wavefront = false;
     h->auto_variant = true;
     h->wf_dynamic_fetch = 32;
-    memset(h->wf_queue, 0, sizeof h->wf_queue);
-    h->wf_radiance = nullptr;
-    h->wf_counts = nullptr;
+    memset(h->wf_pipe, 0, sizeof h->wf_pipe);
+    h->wf_stream2 = nullptr;
+    h->wf_fork = nullptr;
+    h->wf_target_mpaths = 0;
     h->wf_sub_capacity = 0;
     h->wf_capacity = 0;
 
@@ -279,16 +289,19 @@ static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sp
 
 static void free_wavefront(pt_context *h)
 {
-    for (int i = 0; i < 2; ++i) {
-        if (h->wf_queue[i].a) (void)hipFree(h->wf_queue[i].a);
-        if (h->wf_queue[i].b) (void)hipFree(h->wf_queue[i].b);
-        if (h->wf_queue[i].c) (void)hipFree(h->wf_queue[i].c);
-        if (h->wf_queue[i].path) (void)hipFree(h->wf_queue[i].path);
+    if (h->wf_stream2) (void)hipStreamSynchronize(h->wf_stream2);
+    for (auto &pipe : h->wf_pipe) {
+        for (auto &q : pipe.queue) {
+            if (q.a) (void)hipFree(q.a);
+            if (q.b) (void)hipFree(q.b);
+            if (q.c) (void)hipFree(q.c);
+            if (q.path) (void)hipFree(q.path);
+        }
+        if (pipe.radiance) (void)hipFree(pipe.radiance);
+        if (pipe.counts) (void)hipFree(pipe.counts);
+        if (pipe.resolved) (void)hipEventDestroy(pipe.resolved);
     }
-    memset(h->wf_queue, 0, sizeof h->wf_queue);
-    if (h->wf_radiance) (void)hipFree(h->wf_radiance);
-    if (h->wf_counts) (void)hipFree(h->wf_counts);
-    h->wf_radiance = nullptr; h->wf_counts = nullptr;
+    memset(h->wf_pipe, 0, sizeof h->wf_pipe);
     h->wf_sub_capacity = 0; h->wf_capacity = 0;
 }
 
@@ -305,6 +318,8 @@ int pt_destroy(pt_handle h)
     if (h->d_internal_buffer) (void)hipFree(h->d_internal_buffer);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    if (h->wf_fork) (void)hipEventDestroy(h->wf_fork);
+    if (h->wf_stream2) (void)hipStreamDestroy(h->wf_stream2);
     delete h;
     return PT_OK;
 }
@@ -578,6 +593,10 @@ int pt_debug_set_tuning(pt_handle h, int key, int value)
         if (value < 0 || value > 64) break;
         h->wf_dynamic_fetch = value;
         return PT_OK;
+    case PT_TUNE_WAVEFRONT_BATCH:
+        if (value < 0 || value > 1024) break;
+        h->wf_target_mpaths = (uint32_t)value;
+        return PT_OK;
     default:
         return fail(h, PT_ERR_INVALID, "pt_debug_set_tuning: unknown key %d", key);
     }
@@ -586,7 +605,7 @@ int pt_debug_set_tuning(pt_handle h, int key, int value)
 
 static uint32_t div_up(uint32_t a, uint32_t b);
 static uint32_t auto_chunks(uint64_t tiles, uint32_t n_iterations);
-static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_per_it, uint32_t n_iterations);
+static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets);
 static bool takes_wavefront(const pt_context *h, uint64_t last_iteration);
 
 int pt_set_memory_limit(pt_handle h, uint64_t bytes)
@@ -605,17 +624,19 @@ int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
     const uint64_t steal_now = h->d_steal ? kStealPoolBytes + kStealMaskBytes : 0;
     const uint64_t tickets_now = (uint64_t)h->tickets_capacity * sizeof(uint32_t);
     const uint64_t counts = (uint64_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
-    const uint64_t wf_now = h->wf_counts ? (uint64_t)h->wf_sub_capacity * kWfSubQueues * 2 * (3 * sizeof(float4) + sizeof(uint2)) +
-                                               h->wf_capacity * 3 * sizeof(float) + counts : 0;
+    const uint64_t wf_set = (uint64_t)h->wf_sub_capacity * kWfSubQueues * 2 * (3 * sizeof(float4) + sizeof(uint2)) +
+                            h->wf_capacity * 3 * sizeof(float) + counts;
+    const uint64_t wf_now = ((h->wf_pipe[0].counts ? 1 : 0) + (h->wf_pipe[1].counts ? 1 : 0)) * wf_set;
     bytes[0] = fixed + steal_now + tickets_now + wf_now;
     // what the next render adds: wavefront queues of one batch, or the scratch pool and tickets
     uint64_t steal_next = steal_now, tickets_next = tickets_now, wf_next = wf_now;
     const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
-    const uint32_t batch_it = n_iterations ? wavefront_batch_iterations(h, paths_per_it, n_iterations) : 0;
+    uint32_t wf_sets = 1;
+    const uint32_t batch_it = n_iterations ? wavefront_batch_iterations(h, paths_per_it, n_iterations, &wf_sets) : 0;
     if (n_iterations && h->scene_ready && takes_wavefront(h, h->iteration + (uint64_t)n_iterations) && batch_it > 0) {
         const uint64_t capacity = paths_per_it * batch_it;
         const uint64_t sub_cap = ((capacity + 255) / 256 + kWfSubQueues - 1) / kWfSubQueues * 256;
-        const uint64_t need = sub_cap * kWfSubQueues * 2 * (3 * sizeof(float4) + sizeof(uint2)) + capacity * 3 * sizeof(float) + counts;
+        const uint64_t need = wf_sets * (sub_cap * kWfSubQueues * 2 * (3 * sizeof(float4) + sizeof(uint2)) + capacity * 3 * sizeof(float) + counts);
         if (need > wf_next) wf_next = need;
     } else if (n_iterations && h->scene_ready && !h->wavefront && h->steal && !h->steal_alloc_failed &&
                (!h->memory_limit || kStealPoolBytes + kStealMaskBytes <= h->memory_limit)) {
@@ -672,26 +693,37 @@ static void fill_params(const pt_context *h, RenderParams &p)
 
 static uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// Paths per wavefront batch the queues are sized for (about 4 GiB of queues + radiance).
-static const uint64_t kWfTargetPaths = 32ull << 20;
+// Paths in flight the wavefront buffers are sized for (about 8 GiB of queues + radiance in two sets).
+// Measured on the 10 007-sphere scene, 1080p x 16 iterations: 16 Mi paths 111 ms, 32 Mi 97, 64 Mi
+// 92.7, 128 Mi 90.8 -- every launch ends with a tail of its longest traversals, and the fewer and
+// larger the launches the less that costs.
+static const uint64_t kWfTargetPaths = 64ull << 20;
 // Device memory per path of a wavefront batch: two queues of 56-byte path records + the path's radiance.
 static const uint64_t kWfBytesPerPath = 2 * (3 * sizeof(float4) + sizeof(uint2)) + 3 * sizeof(float);
 
 // Iterations per wavefront batch of a frame with `paths_per_it` paths per iteration, within the
-// handle's memory limit; 0 when not even one iteration fits.
-static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_per_it, uint32_t n_iterations)
+// handle's memory limit; 0 when not even one iteration fits.  A render of more iterations than
+// that runs as several batches alternating between two buffer sets of half the size each
+// (*sets = 2); when half the memory does not hold one iteration, one set takes all of it.
+static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets = nullptr)
 {
-    uint64_t target = kWfTargetPaths;
+    uint64_t target = h->wf_target_mpaths ? (uint64_t)h->wf_target_mpaths << 20 : kWfTargetPaths;
     if (h->memory_limit && h->memory_limit / kWfBytesPerPath < target) target = h->memory_limit / kWfBytesPerPath;
-    uint64_t batch_it = target / paths_per_it;
-    if (batch_it < 1) batch_it = h->memory_limit ? 0 : 1;
+    uint32_t n_sets = 2;
+    uint64_t batch_it = target / 2 / paths_per_it;
+    if (batch_it < 1 || batch_it >= n_iterations) {
+        n_sets = 1;
+        batch_it = batch_it < 1 ? target / paths_per_it : batch_it;
+        if (batch_it < 1) batch_it = h->memory_limit ? 0 : 1;
+    }
     if (batch_it > n_iterations) batch_it = n_iterations;
+    if (sets) *sets = n_sets;
     return (uint32_t)batch_it;
 }
 
-// Queues, per-path radiance and counters for batches of `capacity` paths (kept while they suffice).
-// A failed allocation frees what was allocated and reports PT_ERR_NOMEM.
-static int ensure_wavefront(pt_context *h, uint64_t capacity, uint32_t *sub_capacity, size_t *counts_bytes_out)
+// `sets` sets of queues, per-path radiance and counters for batches of `capacity` paths (kept while
+// they suffice).  A failed allocation frees what was allocated and reports PT_ERR_NOMEM.
+static int ensure_wavefront(pt_context *h, uint64_t capacity, uint32_t sets, size_t *counts_bytes_out)
 {
     const uint64_t blocks = (capacity + 255) / 256;
     const uint64_t sub_cap64 = (blocks + kWfSubQueues - 1) / kWfSubQueues * 256;
@@ -699,29 +731,39 @@ static int ensure_wavefront(pt_context *h, uint64_t capacity, uint32_t *sub_capa
     const uint32_t sub_cap = (uint32_t)sub_cap64;
     const size_t counts_bytes = (size_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
     *counts_bytes_out = counts_bytes;
-    if (capacity > h->wf_capacity || sub_cap > h->wf_sub_capacity || !h->wf_counts) {
+    if (sets > 1 && !h->wf_stream2) {
+        if (hipStreamCreateWithFlags(&h->wf_stream2, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->wf_fork, hipEventDisableTiming) != hipSuccess)
+            return fail(h, PT_ERR_DEVICE, "wavefront variant: cannot create the second stream");
+    }
+    bool have = capacity <= h->wf_capacity && sub_cap <= h->wf_sub_capacity;
+    for (uint32_t k = 0; k < sets; ++k) have = have && h->wf_pipe[k].counts;
+    if (!have) {
         PT_HIP(h, hipStreamSynchronize(h->stream));
         free_wavefront(h);
         const size_t slots = (size_t)sub_cap * kWfSubQueues;
         bool ok = true;
-        for (int i = 0; i < 2 && ok; ++i) {
-            ok = hipMalloc((void **)&h->wf_queue[i].a, slots * sizeof(float4)) == hipSuccess &&
-                 hipMalloc((void **)&h->wf_queue[i].b, slots * sizeof(float4)) == hipSuccess &&
-                 hipMalloc((void **)&h->wf_queue[i].c, slots * sizeof(float4)) == hipSuccess &&
-                 hipMalloc((void **)&h->wf_queue[i].path, slots * sizeof(uint2)) == hipSuccess;
+        for (uint32_t k = 0; k < sets && ok; ++k) {
+            pt_context::WfPipe &pipe = h->wf_pipe[k];
+            for (int i = 0; i < 2 && ok; ++i) {
+                ok = hipMalloc((void **)&pipe.queue[i].a, slots * sizeof(float4)) == hipSuccess &&
+                     hipMalloc((void **)&pipe.queue[i].b, slots * sizeof(float4)) == hipSuccess &&
+                     hipMalloc((void **)&pipe.queue[i].c, slots * sizeof(float4)) == hipSuccess &&
+                     hipMalloc((void **)&pipe.queue[i].path, slots * sizeof(uint2)) == hipSuccess;
+            }
+            ok = ok && hipMalloc((void **)&pipe.radiance, capacity * 3 * sizeof(float)) == hipSuccess &&
+                 hipMalloc((void **)&pipe.counts, counts_bytes) == hipSuccess &&
+                 hipEventCreateWithFlags(&pipe.resolved, hipEventDisableTiming) == hipSuccess;
         }
-        ok = ok && hipMalloc((void **)&h->wf_radiance, capacity * 3 * sizeof(float)) == hipSuccess &&
-             hipMalloc((void **)&h->wf_counts, counts_bytes) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
             free_wavefront(h);
-            return fail(h, PT_ERR_NOMEM, "wavefront variant: cannot allocate queues for %llu paths (%llu MiB)",
-                        (unsigned long long)capacity, (unsigned long long)(capacity * kWfBytesPerPath >> 20));
+            return fail(h, PT_ERR_NOMEM, "wavefront variant: cannot allocate queues for %u x %llu paths (%llu MiB)", sets,
+                        (unsigned long long)capacity, (unsigned long long)(sets * capacity * kWfBytesPerPath >> 20));
         }
         h->wf_capacity = capacity;
         h->wf_sub_capacity = sub_cap;
     }
-    *sub_capacity = h->wf_sub_capacity;
     return PT_OK;
 }
 
@@ -734,23 +776,29 @@ static void fill_wavefront(const pt_context *h, WavefrontParams &p)
     p.max_bounces = h->max_bounces;
     p.dynamic_fetch = h->wf_dynamic_fetch;
     p.sub_capacity = h->wf_sub_capacity;
-    p.counts = h->wf_counts;
-    p.path_radiance = h->wf_radiance;
     p.x0 = 0; p.y0 = 0; p.rect_w = p.cam.width; p.rect_h = p.cam.height;
 }
 
-// One batch: a launch per bounce over the compacted queues, then the resolve.
-static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, size_t counts_bytes)
+// One batch in buffer set `set` on `stream`: a launch per bounce over the compacted queues, then
+// the resolve -- after the resolve of the batch before (`after`, the other set's event, or null):
+// the frame buffer takes the batches' iterations in order.
+static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, size_t counts_bytes, int set, hipStream_t stream,
+                                  hipEvent_t after)
 {
     const bool tiled = scene_streams(p.scene);
-    PT_HIP(h, hipMemsetAsync(h->wf_counts, 0, counts_bytes, h->stream));
+    pt_context::WfPipe &pipe = h->wf_pipe[set];
+    p.counts = pipe.counts;
+    p.path_radiance = pipe.radiance;
+    PT_HIP(h, hipMemsetAsync(pipe.counts, 0, counts_bytes, stream));
     for (int b = 0; b <= h->max_bounces; ++b) {
         p.bounce = b;
-        p.out = h->wf_queue[b & 1];
-        p.in = h->wf_queue[(b & 1) ^ 1];
-        PT_HIP(h, launch_wavefront_step(p, tiled, h->stream));
+        p.out = pipe.queue[b & 1];
+        p.in = pipe.queue[(b & 1) ^ 1];
+        PT_HIP(h, launch_wavefront_step(p, tiled, stream));
     }
-    PT_HIP(h, launch_wavefront_resolve(p, h->stream));
+    if (after) PT_HIP(h, hipStreamWaitEvent(stream, after, 0));
+    PT_HIP(h, launch_wavefront_resolve(p, stream));
+    PT_HIP(h, hipEventRecord(pipe.resolved, stream));
     return PT_OK;
 }
 
@@ -762,13 +810,13 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
     const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
     if (h->iteration + (uint64_t)n_iterations >= (1u << 30))
         return fail(h, PT_ERR_INVALID, "wavefront variant: iteration numbers must stay below 2^30");
-    const uint32_t batch_it = wavefront_batch_iterations(h, paths_per_it, n_iterations);
+    uint32_t sets = 1;
+    const uint32_t batch_it = wavefront_batch_iterations(h, paths_per_it, n_iterations, &sets);
     if (batch_it == 0)
         return fail(h, PT_ERR_NOMEM, "wavefront variant: one iteration needs %llu MiB of queues, the memory limit is %llu MiB",
                     (unsigned long long)(paths_per_it * kWfBytesPerPath >> 20), (unsigned long long)(h->memory_limit >> 20));
-    uint32_t sub_cap = 0;
     size_t counts_bytes = 0;
-    const int rc = ensure_wavefront(h, paths_per_it * batch_it, &sub_cap, &counts_bytes);
+    const int rc = ensure_wavefront(h, paths_per_it * batch_it, sets, &counts_bytes);
     if (rc != PT_OK) return rc;
 
     WavefrontParams p;
@@ -778,17 +826,27 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
     p.ray_counter = h->d_ray_counter;
 
     PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
+    if (sets > 1) {   // the second stream starts after what the caller's stream holds so far
+        PT_HIP(h, hipEventRecord(h->wf_fork, h->stream));
+        PT_HIP(h, hipStreamWaitEvent(h->wf_stream2, h->wf_fork, 0));
+    }
     uint32_t done = 0;
+    int set = 0;
+    hipEvent_t before = nullptr;
     while (done < n_iterations) {
         const uint32_t n = n_iterations - done < batch_it ? n_iterations - done : batch_it;
         p.first_iteration = h->iteration + done + 1;
         p.n_iterations = n;
         p.overwrite = h->accum_mode == PT_ACCUM_RUNNING_MEAN ? (p.first_iteration == 1)
                                                              : ((h->fresh && done == 0) ? 1 : 0);
-        const int brc = launch_wavefront_batch(h, p, counts_bytes);
+        const int brc = launch_wavefront_batch(h, p, counts_bytes, set, set ? h->wf_stream2 : h->stream, before);
         if (brc != PT_OK) return brc;
+        before = h->wf_pipe[set].resolved;
         done += n;
+        if (sets > 1) set ^= 1;
     }
+    // the caller's stream ends behind the last resolve (its own, which waited for the other's, or the other's)
+    if (before == h->wf_pipe[1].resolved) PT_HIP(h, hipStreamWaitEvent(h->stream, before, 0));
     PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
     h->timed = true;
     h->iteration += n_iterations;
@@ -1125,9 +1183,8 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
     // The rectangle goes through the kernels a render of this instance would use: the per-bounce
     // wavefront launches, the work-stealing megakernel, or the plain one.
     if (takes_wavefront(h, iteration) && h->integrator == PT_INTEGRATOR_PATH && iteration < (1u << 30)) {
-        uint32_t sub_cap = 0;
         size_t counts_bytes = 0;
-        rc = ensure_wavefront(h, n_paths, &sub_cap, &counts_bytes);
+        rc = ensure_wavefront(h, n_paths, 1, &counts_bytes);
         if (rc != PT_OK) goto cleanup;
         WavefrontParams p;
         fill_wavefront(h, p);
@@ -1139,10 +1196,10 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
         p.buffer = nullptr;
         p.ray_counter = d_cnt;
         p.hit_ids = d_hits; p.pixel_rgb = d_rgb;
-        rc = launch_wavefront_batch(h, p, counts_bytes);
+        rc = launch_wavefront_batch(h, p, counts_bytes, 0, h->stream, nullptr);
         if (rc != PT_OK) goto cleanup;
         // the batch's per-path radiance buffer has the layout of `radiance`
-        if (radiance) DBG_HIP(hipMemcpyAsync(radiance, h->wf_radiance, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        if (radiance) DBG_HIP(hipMemcpyAsync(radiance, h->wf_pipe[0].radiance, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     } else {
         RenderParams p;
         fill_params(h, p);

@@ -142,22 +142,20 @@ PT_DEV void sphere_test_lex(float4 s, int index, V3 o, V3 d, float &tmax, int &b
 
 // The ray as the slab tests see it.  A box plane is stored as a 16-bit grid coordinate q (plane =
 // origin + q * step) and reaches the test as the float 2^23 + q (its bits are 0x4b000000 | q: no
-// conversion instruction).  t(plane) = (2^23 + q) * inv + k with inv = step / direction, and k
-// holds the rest: (origin - o -+ e) / direction - 2^23 * inv, the per-ray widening `e` of the boxes
-// folded in (klo for lower planes, khi for upper ones).  The fused multiply-add rounds once; what k
-// loses to the large constant is below half a grid step, which the builder's outward rounding covers.
+// conversion instruction).  The boxes are widened per ray by w(t) = a + s * t, growing along the ray
+// (see bvh_begin).  On one axis the point o + t * d is inside the widened slab when
+//     t * (d + s) >= lo - a - o   and   t * (d - s) <= hi + a - o,
+// so the two planes get different slopes: t(lower plane) = (2^23 + q) * inv_lo + klo with inv_lo =
+// step / (d + s), klo = (origin - a - o) / (d + s) - 2^23 * inv_lo, and t(upper plane) likewise with
+// d - s and + a.  For |d| > s the smaller of the two is where the ray enters the slab and the larger
+// where it leaves it (when the pair comes out in the other order both are negative, and the box is
+// dropped as lying behind the origin either way).  For |d| <= s the slab grows at least as fast as
+// the ray moves across it: both conditions are lower bounds on t, and the one of the plane the ray
+// moves away from is dropped (its t is replaced by 3e38: "never leaves").  The fused multiply-add
+// rounds once; what k loses to the large constant is below half a grid step, which the builder's
+// outward rounding covers.
 struct BvhRay {
-    V3 inv, klo, khi;
-    PT_DEV void set_direction(const BvhParams &B, V3 inv_dir)
-    {
-        inv = mk(inv_dir.x * B.grid_step[0], inv_dir.y * B.grid_step[1], inv_dir.z * B.grid_step[2]);
-    }
-    PT_DEV void widen(const BvhParams &B, V3 inv_dir, V3 o, float e)
-    {
-        const float gx = B.grid_origin[0] - o.x, gy = B.grid_origin[1] - o.y, gz = B.grid_origin[2] - o.z;
-        klo = mk((gx - e) * inv_dir.x - 8388608.f * inv.x, (gy - e) * inv_dir.y - 8388608.f * inv.y, (gz - e) * inv_dir.z - 8388608.f * inv.z);
-        khi = mk((gx + e) * inv_dir.x - 8388608.f * inv.x, (gy + e) * inv_dir.y - 8388608.f * inv.y, (gz + e) * inv_dir.z - 8388608.f * inv.z);
-    }
+    V3 inv_lo, inv_hi, klo, khi;
 };
 
 // The two 16-bit grid coordinates of a node word as the floats 2^23 + q.
@@ -168,19 +166,19 @@ PT_DEV float qplane_hi(uint32_t w) { return __uint_as_float(__builtin_amdgcn_ali
 // arithmetic only decides which boxes are visited (its rounding is covered by the widening),
 // it never reaches a result.  NaN-conservative: the negated comparisons enter on NaN.
 PT_DEV bool slab_test(float lx, float ly, float lz, float hx, float hy, float hz, const BvhRay &r, float tmax,
-                      float &tnear, float &tfar)
+                      float &tnear)
 {
-    const float t1x = __builtin_fmaf(lx, r.inv.x, r.klo.x), t2x = __builtin_fmaf(hx, r.inv.x, r.khi.x);
-    const float t1y = __builtin_fmaf(ly, r.inv.y, r.klo.y), t2y = __builtin_fmaf(hy, r.inv.y, r.khi.y);
-    const float t1z = __builtin_fmaf(lz, r.inv.z, r.klo.z), t2z = __builtin_fmaf(hz, r.inv.z, r.khi.z);
+    const float t1x = __builtin_fmaf(lx, r.inv_lo.x, r.klo.x), t2x = __builtin_fmaf(hx, r.inv_hi.x, r.khi.x);
+    const float t1y = __builtin_fmaf(ly, r.inv_lo.y, r.klo.y), t2y = __builtin_fmaf(hy, r.inv_hi.y, r.khi.y);
+    const float t1z = __builtin_fmaf(lz, r.inv_lo.z, r.klo.z), t2z = __builtin_fmaf(hz, r.inv_hi.z, r.khi.z);
     tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
                             __builtin_fminf(t1z, t2z));
-    tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
-                           __builtin_fmaxf(t1z, t2z));
+    const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
+                                       __builtin_fmaxf(t1z, t2z));
     return !(tnear > tfar) && !(tfar < 0.f) && !(tnear > tmax);
 }
 
-// Per-ray constants of the box widening, see intersect_bvh.
+// Per-ray constants of the box widening, see bvh_begin.
 struct BvhMargin {
     float eps;     // max(|dir|^2 - 1, 0) + rounding allowance
     float err;     // 1e-6 * L^2 * |dir|^2: rounding error of the sphere test's discriminant
@@ -194,28 +192,6 @@ struct BvhMargin {
         return E2 * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(r_min * r_min + E2) * 0.999999f + r_min) * 1.001f + slack;
     }
 };
-
-// One child box: widened for hits anywhere up to T0 first (`ray`, widening e0); rays whose
-// direction is noticeably longer than 1 then narrow the widening to what hits inside this box
-// can need (their t cannot exceed the exit distance of the widely widened box) and test again.
-PT_DEV bool bvh_box_test(const BvhParams &B, float lx, float ly, float lz, float hx, float hy, float hz, const BvhRay &ray,
-                         V3 o, float e0, bool refine, const BvhMargin &m, float tmax, float &tnear)
-{
-    float tfar;
-    bool hit = slab_test(lx, ly, lz, hx, hy, hz, ray, tmax, tnear, tfar);
-    if (hit && refine) {
-        PT_LS(22);
-        const float e1 = m.at(__builtin_fminf(tfar * 1.00001f, tmax));
-        if (e1 < e0) {
-            BvhRay narrow;
-            narrow.inv = ray.inv;
-            // 1 / direction again, from the stored step / direction
-            narrow.widen(B, mk(ray.inv.x * B.grid_inv_step[0], ray.inv.y * B.grid_inv_step[1], ray.inv.z * B.grid_inv_step[2]), o, e1);
-            hit = slab_test(lx, ly, lz, hx, hy, hz, narrow, tmax, tnear, tfar);
-        }
-    }
-    return hit;
-}
 
 // 1 / x for the slab tests, finite for every finite or zero x (a zero component becomes a tiny
 // one: the ray then leaves the scene's extent along that axis only after ~1e18 units).
@@ -255,12 +231,16 @@ PT_DEV bool bvh_pop(const Stack &stack, int &sp, float tmax, int &cur)
 // A box is entered when the ray's slab interval through the widened box overlaps [0, tmax].
 // The widening is per ray: a valid t of the fp32 sphere test puts origin + t * dir at squared
 // distance r^2 + (|dir|^2 - 1) * t^2 + err from the centre, err < 1e-6 * |op|^2 * |dir|^2, op =
-// centre - origin (derivation in pt_bvh.cpp).  With eps >= |dir|^2 - 1, T >= t and L >= |op| for every
-// bounded sphere, e(T) = sqrt(r_min^2 + eps * T^2 + err(L)) - r_min covers all of them (the
-// excess shrinks as r grows); the slab arithmetic's own rounding is added on top.  Mirror
-// directions are not re-normalised (globals.h:107-109) and can be several per cent too long
-// after a bounce off a small sphere, so eps is not always tiny.  t itself is below tmax and
-// below (2 |dir| + 0.1) L: the hit lies about r from a centre, and |op| + r <= L.
+// centre - origin (derivation in pt_bvh.cpp).  With eps >= |dir|^2 - 1 and L >= |op| for every
+// bounded sphere, the hit point lies within e(t) = sqrt(r_min^2 + eps * t^2 + err(L)) - r_min of
+// the sphere's box (the excess shrinks as r grows); the slab arithmetic's own rounding is added on
+// top.  Mirror directions are not re-normalised (globals.h:107-109) and can be several per cent too
+// long after a bounce off a small sphere, so eps is not always tiny and e grows to tens of units
+// at the far end of such a ray.  t itself is below tmax and below T0 = (2 |dir| + 0.1) L: the hit
+// lies about r from a centre, and |op| + r <= L.  e(t) is convex (the norm of (sqrt(r_min^2 + err),
+// sqrt(eps) t) minus a constant), so on [0, T0] it stays below the chord through its end points:
+// the boxes are widened by w(t) = a + s * t with a >= e(0) and a + s * T0 >= e(T0), narrow near the
+// origin and wide far away, and BvhRay turns that into two slopes per axis at no cost per box.
 // A skipped box therefore cannot hold a sphere whose test would succeed with t <= tmax, and
 // sphere_test_lex makes the visiting order irrelevant: the result equals the brute-force scan's.
 //
@@ -273,12 +253,12 @@ PT_DEV bool bvh_pop(const Stack &stack, int &sp, float tmax, int &cur)
 
 
 struct BvhTraversal {
-    BvhMargin m;
     BvhRay ray;
-    float e;           // widening for hits anywhere up to the ray's initial bound
-    bool refine;       // direction noticeably longer than 1: narrow the widening per box
     int cur, sp;       // current node reference and stack height
     uint32_t visits;
+#ifdef PT_BVH_STATS
+    bool long_direction;
+#endif
 };
 
 // Starts a traversal: tests the always-tested spheres, derives the ray's widening and slab
@@ -289,19 +269,39 @@ PT_DEV bool bvh_begin(const BvhParams &B, V3 o, V3 d, float &tmax, int &best, Bv
     const float cx = o.x - B.centre[0], cy = o.y - B.centre[1], cz = o.z - B.centre[2];
     const float L = __builtin_amdgcn_sqrtf(cx * cx + cy * cy + cz * cz) * 1.000002f + B.half_diag;
     const float excess = (d.x * d.x + d.y * d.y + d.z * d.z) - 1.f;
-    tr.m.eps = __builtin_fmaxf(excess, 0.f) * 1.000001f + 4e-7f;
+    BvhMargin m;
+    m.eps = __builtin_fmaxf(excess, 0.f) * 1.000001f + 4e-7f;
     // b = op . dir grows with |dir|, and with it the rounding errors of b * b and of t = b -+ sqrt(det)
-    tr.m.err = 1e-6f * L * L * (1.f + tr.m.eps);
+    m.err = 1e-6f * L * L * (1.f + m.eps);
     // slab arithmetic: plane * inv + k cancels two terms of the size of the coordinates
-    tr.m.slack = (2e-6f * L + 4e-7f * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z))) * (1.f + tr.m.eps);
-    tr.m.r_min = B.r_min;
-    tr.e = tr.m.at(__builtin_fminf(tmax, (2.2f * (1.f + tr.m.eps) + 0.1f) * L));
-    tr.refine = tr.m.eps > 2e-6f;
-    // overflow (absurdly long directions, far origins): visit everything, like the scan
-    if (!(tr.e < 3.0e38f)) { tr.e = PT_INF; tr.refine = false; }
-    const V3 inv_dir = mk(bvh_inverse(d.x), bvh_inverse(d.y), bvh_inverse(d.z));
-    tr.ray.set_direction(B, inv_dir);
-    tr.ray.widen(B, inv_dir, o, tr.e);
+    m.slack = (2e-6f * L + 4e-7f * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z))) * (1.f + m.eps);
+    m.r_min = B.r_min;
+    // the chord of e(t) over [0, T0]; e(0) - slack >= 0 makes (e(T0) - slack) / T0 a large enough slope
+    const float T0 = __builtin_fminf(tmax, (2.2f * (1.f + m.eps) + 0.1f) * L);
+    float a = m.at(0.f);
+    float s = (m.at(T0) - m.slack) * __builtin_amdgcn_rcpf(T0) * 1.00001f;
+    // overflow (absurdly long directions, far origins, an empty search interval): visit everything, like the scan
+    if (!(s < 3.0e38f)) { a = PT_INF; s = 0.f; }
+#ifdef PT_BVH_STATS
+    tr.long_direction = m.eps > 2e-6f;
+#endif
+    const float g[3] = {B.grid_origin[0] - o.x, B.grid_origin[1] - o.y, B.grid_origin[2] - o.z};
+    const float dir[3] = {d.x, d.y, d.z};
+    float il[3], ih[3], kl[3], kh[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const float p = bvh_inverse(dir[ax] + s), q = bvh_inverse(dir[ax] - s);
+        il[ax] = p * B.grid_step[ax];
+        ih[ax] = q * B.grid_step[ax];
+        kl[ax] = (g[ax] - a) * p - 8388608.f * il[ax];
+        kh[ax] = (g[ax] + a) * q - 8388608.f * ih[ax];
+        if (!(__builtin_fabsf(dir[ax]) > s)) {   // the slab outgrows the ray's motion across it
+            if (dir[ax] < 0.f) { il[ax] = 0.f; kl[ax] = 3.0e38f; }
+            else               { ih[ax] = 0.f; kh[ax] = 3.0e38f; }
+        }
+    }
+    tr.ray.inv_lo = mk(il[0], il[1], il[2]); tr.ray.inv_hi = mk(ih[0], ih[1], ih[2]);
+    tr.ray.klo = mk(kl[0], kl[1], kl[2]);    tr.ray.khi = mk(kh[0], kh[1], kh[2]);
     tr.cur = 0; tr.sp = 0; tr.visits = 0;
     // a NaN in the origin or the direction makes every sphere test fail (all comparisons false)
     return !(excess != excess || L != L);
@@ -313,7 +313,7 @@ PT_DEV bool bvh_begin(const BvhParams &B, V3 o, V3 d, float &tmax, int &best, Bv
 // traversal is finished (stack empty).  A full stack makes the ray give up the tree: its visit
 // count is set beyond any budget, so that the caller finishes it by the wave-wide scan.
 template <class Stack>
-PT_DEV bool bvh_node_step(const BvhParams &B, const uint4 *nodes, const Stack &stack, V3 o, float tmax, BvhTraversal &tr)
+PT_DEV bool bvh_node_step(const BvhParams &B, const uint4 *nodes, const Stack &stack, float tmax, BvhTraversal &tr)
 {
     PT_LS(23);
     const uint4 *N = nodes + 4 * (size_t)tr.cur;   // device memory, or the workgroup's copy in LDS
@@ -321,18 +321,16 @@ PT_DEV bool bvh_node_step(const BvhParams &B, const uint4 *nodes, const Stack &s
     const int c0 = (int)rf.x, c1 = (int)rf.y, c2 = (int)rf.z, c3 = (int)rf.w;
     float t0, t1, t2, t3;
     // words: q0 = (lo.x c0|c1, lo.x c2|c3, lo.y c0|c1, lo.y c2|c3), q1 = (lo.z, lo.z, hi.x, hi.x), q2 = (hi.y, hi.y, hi.z, hi.z)
-    // (testing all four boxes first and re-testing the hit ones of over-long directions in one
-    // branch afterwards keeps 24 planes alive and measured 30 % slower)
-    const bool h0 = bvh_box_test(B, qplane_lo(q0.x), qplane_lo(q0.z), qplane_lo(q1.x), qplane_lo(q1.z), qplane_lo(q2.x), qplane_lo(q2.z),
-                                 tr.ray, o, tr.e, tr.refine, tr.m, tmax, t0);   // slots 0 and 1 are always used
-    const bool h1 = bvh_box_test(B, qplane_hi(q0.x), qplane_hi(q0.z), qplane_hi(q1.x), qplane_hi(q1.z), qplane_hi(q2.x), qplane_hi(q2.z),
-                                 tr.ray, o, tr.e, tr.refine, tr.m, tmax, t1);
+    const bool h0 = slab_test(qplane_lo(q0.x), qplane_lo(q0.z), qplane_lo(q1.x), qplane_lo(q1.z), qplane_lo(q2.x), qplane_lo(q2.z),
+                                 tr.ray, tmax, t0);   // slots 0 and 1 are always used
+    const bool h1 = slab_test(qplane_hi(q0.x), qplane_hi(q0.z), qplane_hi(q1.x), qplane_hi(q1.z), qplane_hi(q2.x), qplane_hi(q2.z),
+                                 tr.ray, tmax, t1);
     const bool h2 = c2 != 0x7fffffff &&
-                    bvh_box_test(B, qplane_lo(q0.y), qplane_lo(q0.w), qplane_lo(q1.y), qplane_lo(q1.w), qplane_lo(q2.y), qplane_lo(q2.w),
-                                 tr.ray, o, tr.e, tr.refine, tr.m, tmax, t2);
+                    slab_test(qplane_lo(q0.y), qplane_lo(q0.w), qplane_lo(q1.y), qplane_lo(q1.w), qplane_lo(q2.y), qplane_lo(q2.w),
+                                 tr.ray, tmax, t2);
     const bool h3 = c3 != 0x7fffffff &&
-                    bvh_box_test(B, qplane_hi(q0.y), qplane_hi(q0.w), qplane_hi(q1.y), qplane_hi(q1.w), qplane_hi(q2.y), qplane_hi(q2.w),
-                                 tr.ray, o, tr.e, tr.refine, tr.m, tmax, t3);
+                    slab_test(qplane_hi(q0.y), qplane_hi(q0.w), qplane_hi(q1.y), qplane_hi(q1.w), qplane_hi(q2.y), qplane_hi(q2.w),
+                                 tr.ray, tmax, t3);
     ++tr.visits;
     // nearest hit child (NaN entry distances lose against everything, which is fine: they are only a visiting order)
     int near_slot = -1;
@@ -419,7 +417,7 @@ PT_DEV void intersect_bvh(const BvhParams &B, const float4 *sph, uint32_t n_prim
             if (more && tr.cur >= 0) {
                 PT_BVH_COUNT(st_nodes);
                 PT_BVH_WAVE_COUNT(st_wave_nodes);
-                more = bvh_node_step(B, B.nodes, stack, o, tmax, tr);
+                more = bvh_node_step(B, B.nodes, stack, tmax, tr);
                 if (tr.visits > B.budget) { over_budget = more; more = false; }
             }
         }
@@ -438,7 +436,7 @@ PT_DEV void intersect_bvh(const BvhParams &B, const float4 *sph, uint32_t n_prim
         if (over_budget) atomicAdd(B.stats + 3, 1ull);
         atomicAdd(B.stats + 4, (unsigned long long)st_wave_nodes);
         atomicAdd(B.stats + 5, (unsigned long long)st_wave_leaves);
-        if (tr.refine) atomicAdd(B.stats + 7, 1ull);
+        if (tr.long_direction) atomicAdd(B.stats + 7, 1ull);
         atomicAdd(B.stats + 8 + (31 - __clz((int)(st_nodes + st_leaves + 1))), 1ull);   // log2 histogram of steps
     }
     if (st_leader) atomicAdd(B.stats + 6, 1ull);

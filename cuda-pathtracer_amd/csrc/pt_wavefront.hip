@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
     float tmax = PT_INF;
     int best = -1;
     BvhTraversal tr;
-    tr.cur = 0; tr.sp = 0; tr.visits = 0; tr.e = 0.f; tr.refine = false;
+    tr.cur = 0; tr.sp = 0; tr.visits = 0;
 
     for (;;) {
         // ---- refill idle lanes ---------------------------------------------------------------
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
 #pragma unroll 1
             for (uint32_t k = 0; k < B.node_steps; ++k) {
                 if (trav && tr.cur >= 0) {
-                    trav = bvh_node_step(B, nodes, stack, o, tmax, tr);
+                    trav = bvh_node_step(B, nodes, stack, tmax, tr);
                     if (tr.visits > B.budget) { over = trav; trav = false; }
                 }
             }

@@ -170,9 +170,12 @@ int pt_reset_counters(pt_handle h);
  *   PT_VARIANT_REGENERATION: megakernel, persistent lanes with path regeneration
  *   PT_VARIANT_CLASSIC: megakernel, a wave starts new paths only when all its lanes are idle
  *   PT_VARIANT_WAVEFRONT: one launch per bounce over compacted path queues in device memory
- *     (124 bytes per path of a batch, up to about 4 GiB, allocated on first use -- see
- *     pt_memory_footprint; no row bands).  BVH scenes: persistent waves that refill idle lanes
- *     from the queue while the other lanes keep traversing
+ *     (124 bytes per path in flight, up to about 8 GiB, allocated on first use -- see
+ *     pt_memory_footprint and pt_set_memory_limit; no row bands).  A render of more iterations
+ *     than fit runs as batches that alternate between two buffer sets on two streams (the
+ *     caller's and one of the instance's), so that one batch's launches fill the chip while the
+ *     other's last traversals finish; the caller's stream ends behind both.  BVH scenes:
+ *     persistent waves that refill idle lanes from the queue while the other lanes keep traversing
  * Selecting a variant resets the tuning knobs below to their defaults. */
 enum { PT_VARIANT_AUTO = -1, PT_VARIANT_REGENERATION = 0, PT_VARIANT_CLASSIC = 1, PT_VARIANT_WAVEFRONT = 100,
        PT_VARIANT_STEALING = 500 };
@@ -192,9 +195,11 @@ int pt_set_kernel_variant(pt_handle h, int variant);
  *                              reset by pt_init_scene, not by pt_set_kernel_variant)
  *   PT_TUNE_BVH_STACK          entries of the per-lane traversal stack (0: the default, two per
  *                              tree level + 2; a ray that runs out is finished by the wave-wide
- *                              scan; reset by pt_init_scene) */
+ *                              scan; reset by pt_init_scene)
+ *   PT_TUNE_WAVEFRONT_BATCH    paths per wavefront batch in units of 2^20 (0: the default; 124 bytes
+ *                              of queues and radiance per path; kept across variant changes) */
 enum { PT_TUNE_REGEN_MIN_IDLE = 0, PT_TUNE_CAMERA_RAY_RING = 1, PT_TUNE_STEAL_UNIT = 2, PT_TUNE_ITERATION_RANGES = 3,
-       PT_TUNE_WAVEFRONT_REFILL = 4, PT_TUNE_BVH_NODE_STEPS = 5, PT_TUNE_BVH_STACK = 6 };
+       PT_TUNE_WAVEFRONT_REFILL = 4, PT_TUNE_BVH_NODE_STEPS = 5, PT_TUNE_BVH_STACK = 6, PT_TUNE_WAVEFRONT_BATCH = 7 };
 int pt_debug_set_tuning(pt_handle h, int key, int value);
 /* Device memory held by the instance: bytes[0] = allocated now (scene, BVH, scratch pool,
  * tickets, wavefront queues, internal frame buffer); bytes[1] = what a pt_run_n of n_iterations

@@ -725,4 +725,18 @@ def test_variants_tuning_and_memory_footprint(pt, torch_cuda):
     tr.SetMemoryLimit(124 * 256 * 128 * 4 + 2**20)                 # one iteration per batch
     tr.SetKernelVariant(pt.VARIANT_AUTO)
     assert render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes() == ref
+    # room for two iterations: two buffer sets of one iteration each, batches alternating between
+    # them on two streams, folded into the frame in iteration order
+    tr.SetMemoryLimit(0)
+    ref5 = render(torch_cuda, tr, 1, 5).cpu().numpy().tobytes()
+    tr.Release()
+    tr = pt.Pathtracer(cam, 8, 1)
+    tr.Init(mats, sph, lights)
+    tr.SetMemoryLimit(2 * 124 * 256 * 128 * 4 + 2**20)
+    now, nxt = tr.MemoryFootprint(5)
+    assert 2 * 124 * 256 * 128 * 4 <= nxt - now <= 2 * 124 * 256 * 128 * 4 + 2**20
+    assert render(torch_cuda, tr, 1, 5).cpu().numpy().tobytes() == ref5
+    assert tr.MemoryFootprint(5) == (nxt, nxt)
+    tr.SetTuning(pt.TUNE_WAVEFRONT_BATCH, 1)                       # 2^20 paths in flight: eight iterations, four per set
+    assert render(torch_cuda, tr, 1, 5).cpu().numpy().tobytes() == ref5
     tr.Release()
