@@ -67,14 +67,16 @@ def flops_per_ray(n_spheres: int) -> int:
 def flops_per_ray_bvh(workload: str):
     """With the sphere BVH the work per Intersect call depends on the ray: the average visit
     counts come from the committed run of the counting build (tools/stats, pt_accel_stats):
-    44 flops per inner node (two boxes: 6 fma + 10 min/max each), 4 sphere tests per leaf, plus
-    the always-tested spheres and the bounce's shading.  None when no count is committed."""
+    22 flops per child box of an inner node (6 fma + 10 min/max; four boxes per node), 4 sphere
+    tests per leaf, plus the always-tested spheres and the bounce's shading.  None when no count
+    is committed."""
     path = os.path.join(ROOT, "profiles", f"bvh_visits_{workload}.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
         v = json.load(f)
-    return 121 + 17 * v["always_tested_spheres"] + 44 * v["inner_per_ray"] + 4 * 17 * v["leaves_per_ray"]
+    return (121 + 17 * v["always_tested_spheres"] + 22 * v.get("node_width", 2) * v["inner_per_ray"]
+            + 4 * 17 * v["leaves_per_ray"])
 
 
 def host_description():

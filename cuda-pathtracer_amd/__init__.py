@@ -43,7 +43,7 @@ VARIANT_AUTO, VARIANT_REGENERATION, VARIANT_CLASSIC, VARIANT_WAVEFRONT, VARIANT_
 ACCEL_AUTO, ACCEL_BRUTE_FORCE = 0, 1
 INTEGRATOR_PATH, INTEGRATOR_NEE_MIS = 0, 1
 TUNE_REGEN_MIN_IDLE, TUNE_CAMERA_RAY_RING, TUNE_STEAL_UNIT, TUNE_ITERATION_RANGES, TUNE_WAVEFRONT_REFILL = 0, 1, 2, 3, 4
-TUNE_BVH_NODE_STEPS, TUNE_BVH_STACK, TUNE_WAVEFRONT_BATCH = 5, 6, 7
+TUNE_BVH_NODE_STEPS, TUNE_BVH_STACK, TUNE_WAVEFRONT_BATCH, TUNE_WAVEFRONT_WHOLE_PATHS = 5, 6, 7, 8
 PT_OK, PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_DEVICE, PT_ERR_NOMEM = 0, -1, -2, -3, -4
 
 # Every symbol include/ptmi.h declares: (name, restype, argtypes)

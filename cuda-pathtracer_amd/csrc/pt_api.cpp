@@ -75,6 +75,8 @@ struct pt_context {
     hipStream_t wf_stream2;
     hipEvent_t wf_fork;
     uint32_t wf_target_mpaths;   // paths per wavefront batch in units of 2^20 (0: kWfTargetPaths)
+    int wf_whole_paths;          // BVH scenes with dynamic fetch: whole paths in one launch, no queues
+    bool wf_has_queues;          // the buffer sets include the path queues
     uint32_t wf_sub_capacity;   // paths per sub-queue the buffers were sized for
     uint64_t wf_capacity;       // paths per batch the buffers were sized for
     std::string error;
@@ -197,6 +199,8 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->wf_stream2 = nullptr;
     h->wf_fork = nullptr;
     h->wf_target_mpaths = 0;
+    h->wf_whole_paths = 0;
+    h->wf_has_queues = false;
     h->wf_sub_capacity = 0;
     h->wf_capacity = 0;
 
@@ -303,6 +307,7 @@ static void free_wavefront(pt_context *h)
     }
     memset(h->wf_pipe, 0, sizeof h->wf_pipe);
     h->wf_sub_capacity = 0; h->wf_capacity = 0;
+    h->wf_has_queues = false;
 }
 
 int pt_destroy(pt_handle h)
@@ -594,8 +599,12 @@ int pt_debug_set_tuning(pt_handle h, int key, int value)
         h->wf_dynamic_fetch = value;
         return PT_OK;
     case PT_TUNE_WAVEFRONT_BATCH:
-        if (value < 0 || value > 1024) break;
+        if (value < 0 || value > 4096) break;
         h->wf_target_mpaths = (uint32_t)value;
+        return PT_OK;
+    case PT_TUNE_WAVEFRONT_WHOLE_PATHS:
+        if (value != 0 && value != 1) break;
+        h->wf_whole_paths = value;
         return PT_OK;
     default:
         return fail(h, PT_ERR_INVALID, "pt_debug_set_tuning: unknown key %d", key);
@@ -607,6 +616,7 @@ static uint32_t div_up(uint32_t a, uint32_t b);
 static uint32_t auto_chunks(uint64_t tiles, uint32_t n_iterations);
 static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets);
 static bool takes_wavefront(const pt_context *h, uint64_t last_iteration);
+static bool wavefront_whole_paths(const pt_context *h);
 
 int pt_set_memory_limit(pt_handle h, uint64_t bytes)
 {
@@ -624,7 +634,8 @@ int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
     const uint64_t steal_now = h->d_steal ? kStealPoolBytes + kStealMaskBytes : 0;
     const uint64_t tickets_now = (uint64_t)h->tickets_capacity * sizeof(uint32_t);
     const uint64_t counts = (uint64_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
-    const uint64_t wf_set = (uint64_t)h->wf_sub_capacity * kWfSubQueues * 2 * (3 * sizeof(float4) + sizeof(uint2)) +
+    const uint64_t queue_bytes = 2 * (3 * sizeof(float4) + sizeof(uint2));
+    const uint64_t wf_set = (h->wf_has_queues ? (uint64_t)h->wf_sub_capacity * kWfSubQueues * queue_bytes : 0) +
                             h->wf_capacity * 3 * sizeof(float) + counts;
     const uint64_t wf_now = ((h->wf_pipe[0].counts ? 1 : 0) + (h->wf_pipe[1].counts ? 1 : 0)) * wf_set;
     bytes[0] = fixed + steal_now + tickets_now + wf_now;
@@ -636,7 +647,7 @@ int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
     if (n_iterations && h->scene_ready && takes_wavefront(h, h->iteration + (uint64_t)n_iterations) && batch_it > 0) {
         const uint64_t capacity = paths_per_it * batch_it;
         const uint64_t sub_cap = ((capacity + 255) / 256 + kWfSubQueues - 1) / kWfSubQueues * 256;
-        const uint64_t need = wf_sets * (sub_cap * kWfSubQueues * 2 * (3 * sizeof(float4) + sizeof(uint2)) + capacity * 3 * sizeof(float) + counts);
+        const uint64_t need = wf_sets * ((wavefront_whole_paths(h) ? 0 : sub_cap * kWfSubQueues * queue_bytes) + capacity * 3 * sizeof(float) + counts);
         if (need > wf_next) wf_next = need;
     } else if (n_iterations && h->scene_ready && !h->wavefront && h->steal && !h->steal_alloc_failed &&
                (!h->memory_limit || kStealPoolBytes + kStealMaskBytes <= h->memory_limit)) {
@@ -693,13 +704,34 @@ static void fill_params(const pt_context *h, RenderParams &p)
 
 static uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// Paths in flight the wavefront buffers are sized for (about 8 GiB of queues + radiance in two sets).
-// Measured on the 10 007-sphere scene, 1080p x 16 iterations: 16 Mi paths 111 ms, 32 Mi 97, 64 Mi
-// 92.7, 128 Mi 90.8 -- every launch ends with a tail of its longest traversals, and the fewer and
-// larger the launches the less that costs.
-static const uint64_t kWfTargetPaths = 64ull << 20;
-// Device memory per path of a wavefront batch: two queues of 56-byte path records + the path's radiance.
+// Device memory per path of a wavefront batch: two queues of 56-byte path records + the path's
+// radiance; without the queues (whole paths per launch) the radiance alone.
 static const uint64_t kWfBytesPerPath = 2 * (3 * sizeof(float4) + sizeof(uint2)) + 3 * sizeof(float);
+static const uint64_t kWfBytesPerWholePath = 3 * sizeof(float);
+// Device memory the wavefront buffers are sized for by default (two sets together).
+// Measured on the 10 007-sphere scene, 1080p x 16 iterations, per-bounce launches: 16 Mi paths in
+// flight 111 ms, 32 Mi 97, 64 Mi 92.7, 128 Mi 90.8 -- every launch ends with a tail of its longest
+// traversals, and the fewer and larger the launches the less that costs.
+static const uint64_t kWfTargetBytes = (64ull << 20) * kWfBytesPerPath;
+
+// BVH scenes traced by the persistent waves: does one launch per batch follow every path to its
+// end (no queues, 12 bytes per path) instead of one launch per bounce (124 bytes per path)?
+// Measured on the 10 007-sphere scene, 1080p x 16 iterations: 98.5 ms against 92.7 ms -- the
+// per-bounce launches keep the coherent camera rays (a quarter of all rays, traced at twice the
+// rate of the others) in waves of their own.  So only on request, or when the memory limit has
+// no room for one iteration's queues.
+static bool wavefront_whole_paths(const pt_context *h)
+{
+    if (h->wf_dynamic_fetch <= 0 || h->accel != PT_ACCEL_AUTO || h->bvh.n_nodes == 0) return false;
+    if (h->wf_whole_paths) return true;
+    const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
+    return h->memory_limit && h->memory_limit / kWfBytesPerPath < paths_per_it;
+}
+
+static uint64_t wavefront_bytes_per_path(const pt_context *h)
+{
+    return wavefront_whole_paths(h) ? kWfBytesPerWholePath : kWfBytesPerPath;
+}
 
 // Iterations per wavefront batch of a frame with `paths_per_it` paths per iteration, within the
 // handle's memory limit; 0 when not even one iteration fits.  A render of more iterations than
@@ -707,8 +739,9 @@ static const uint64_t kWfBytesPerPath = 2 * (3 * sizeof(float4) + sizeof(uint2))
 // (*sets = 2); when half the memory does not hold one iteration, one set takes all of it.
 static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets = nullptr)
 {
-    uint64_t target = h->wf_target_mpaths ? (uint64_t)h->wf_target_mpaths << 20 : kWfTargetPaths;
-    if (h->memory_limit && h->memory_limit / kWfBytesPerPath < target) target = h->memory_limit / kWfBytesPerPath;
+    const uint64_t per_path = wavefront_bytes_per_path(h);
+    uint64_t target = h->wf_target_mpaths ? (uint64_t)h->wf_target_mpaths << 20 : kWfTargetBytes / per_path;
+    if (h->memory_limit && h->memory_limit / per_path < target) target = h->memory_limit / per_path;
     uint32_t n_sets = 2;
     uint64_t batch_it = target / 2 / paths_per_it;
     if (batch_it < 1 || batch_it >= n_iterations) {
@@ -725,6 +758,7 @@ static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_p
 // they suffice).  A failed allocation frees what was allocated and reports PT_ERR_NOMEM.
 static int ensure_wavefront(pt_context *h, uint64_t capacity, uint32_t sets, size_t *counts_bytes_out)
 {
+    const bool queues = !wavefront_whole_paths(h);
     const uint64_t blocks = (capacity + 255) / 256;
     const uint64_t sub_cap64 = (blocks + kWfSubQueues - 1) / kWfSubQueues * 256;
     if (sub_cap64 > 0xffffff00ull) return fail(h, PT_ERR_INVALID, "wavefront variant: image too large");
@@ -736,7 +770,7 @@ static int ensure_wavefront(pt_context *h, uint64_t capacity, uint32_t sets, siz
             hipEventCreateWithFlags(&h->wf_fork, hipEventDisableTiming) != hipSuccess)
             return fail(h, PT_ERR_DEVICE, "wavefront variant: cannot create the second stream");
     }
-    bool have = capacity <= h->wf_capacity && sub_cap <= h->wf_sub_capacity;
+    bool have = capacity <= h->wf_capacity && sub_cap <= h->wf_sub_capacity && (h->wf_has_queues || !queues);
     for (uint32_t k = 0; k < sets; ++k) have = have && h->wf_pipe[k].counts;
     if (!have) {
         PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -745,7 +779,7 @@ static int ensure_wavefront(pt_context *h, uint64_t capacity, uint32_t sets, siz
         bool ok = true;
         for (uint32_t k = 0; k < sets && ok; ++k) {
             pt_context::WfPipe &pipe = h->wf_pipe[k];
-            for (int i = 0; i < 2 && ok; ++i) {
+            for (int i = 0; i < 2 && ok && queues; ++i) {
                 ok = hipMalloc((void **)&pipe.queue[i].a, slots * sizeof(float4)) == hipSuccess &&
                      hipMalloc((void **)&pipe.queue[i].b, slots * sizeof(float4)) == hipSuccess &&
                      hipMalloc((void **)&pipe.queue[i].c, slots * sizeof(float4)) == hipSuccess &&
@@ -759,10 +793,11 @@ static int ensure_wavefront(pt_context *h, uint64_t capacity, uint32_t sets, siz
             (void)hipGetLastError();
             free_wavefront(h);
             return fail(h, PT_ERR_NOMEM, "wavefront variant: cannot allocate queues for %u x %llu paths (%llu MiB)", sets,
-                        (unsigned long long)capacity, (unsigned long long)(sets * capacity * kWfBytesPerPath >> 20));
+                        (unsigned long long)capacity, (unsigned long long)(sets * capacity * wavefront_bytes_per_path(h) >> 20));
         }
         h->wf_capacity = capacity;
         h->wf_sub_capacity = sub_cap;
+        h->wf_has_queues = queues;
     }
     return PT_OK;
 }
@@ -776,6 +811,7 @@ static void fill_wavefront(const pt_context *h, WavefrontParams &p)
     p.max_bounces = h->max_bounces;
     p.dynamic_fetch = h->wf_dynamic_fetch;
     p.sub_capacity = h->wf_sub_capacity;
+    p.whole_paths = wavefront_whole_paths(h) ? 1 : 0;
     p.x0 = 0; p.y0 = 0; p.rect_w = p.cam.width; p.rect_h = p.cam.height;
 }
 
@@ -790,7 +826,7 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, size_t coun
     p.counts = pipe.counts;
     p.path_radiance = pipe.radiance;
     PT_HIP(h, hipMemsetAsync(pipe.counts, 0, counts_bytes, stream));
-    for (int b = 0; b <= h->max_bounces; ++b) {
+    for (int b = 0; b <= (p.whole_paths ? 0 : h->max_bounces); ++b) {
         p.bounce = b;
         p.out = pipe.queue[b & 1];
         p.in = pipe.queue[(b & 1) ^ 1];
@@ -814,7 +850,7 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
     const uint32_t batch_it = wavefront_batch_iterations(h, paths_per_it, n_iterations, &sets);
     if (batch_it == 0)
         return fail(h, PT_ERR_NOMEM, "wavefront variant: one iteration needs %llu MiB of queues, the memory limit is %llu MiB",
-                    (unsigned long long)(paths_per_it * kWfBytesPerPath >> 20), (unsigned long long)(h->memory_limit >> 20));
+                    (unsigned long long)(paths_per_it * wavefront_bytes_per_path(h) >> 20), (unsigned long long)(h->memory_limit >> 20));
     size_t counts_bytes = 0;
     const int rc = ensure_wavefront(h, paths_per_it * batch_it, sets, &counts_bytes);
     if (rc != PT_OK) return rc;

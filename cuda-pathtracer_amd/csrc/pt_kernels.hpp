@@ -169,6 +169,7 @@ struct WavefrontParams {
     int dynamic_fetch;          // BVH scenes: persistent waves refill when fewer lanes than this still
                                 // traverse (0: static chunks of 256 paths)
     uint32_t sub_capacity;      // paths per sub-queue, a multiple of 256
+    int whole_paths;            // BVH scenes with dynamic fetch: one launch traces whole paths (no queues)
     uint32_t *counts;           // [max_bounces + 2][kWfSubQueues][kWfCountStride]: word 0 = paths alive
                                 // in sub-queue q entering bounce k, word 1 = fetch cursor of the
                                 // dynamic-fetch kernel over those paths

@@ -51,9 +51,9 @@ PT_DEV size_t batch_path_index(const WavefrontParams &p, uint32_t n_pix, uint32_
 }
 
 // parity hook: primitive index the path's Intersect call of this bounce returned
-PT_DEV void record_hit(const WavefrontParams &p, uint32_t n_pix, uint32_t pix, uint32_t it_sub, int best)
+PT_DEV void record_hit(const WavefrontParams &p, uint32_t n_pix, uint32_t pix, uint32_t it_sub, int bounce, int best)
 {
-    if (p.hit_ids) p.hit_ids[batch_path_index(p, n_pix, pix, it_sub) * (size_t)(p.max_bounces + 1) + p.bounce] = best;
+    if (p.hit_ids) p.hit_ids[batch_path_index(p, n_pix, pix, it_sub) * (size_t)(p.max_bounces + 1) + bounce] = best;
 }
 
 template <bool TILED, bool BVH>
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
         if (active) {
             bool end = true;
             int b = p.bounce;
-            record_hit(p, n_pix, pix, it_sub, best);
+            record_hit(p, n_pix, pix, it_sub, p.bounce, best);
             if (best >= 0) {
                 const float4 s = TILED ? p.scene.sph[best] : sc.sph[best];
                 end = shade_bounce(sc, s, best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
@@ -152,18 +152,24 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
 }
 
 // BVH scenes: the same step with dynamic ray fetch.  A BVH traversal takes a different number of
-// steps for every ray (mean 30 box/leaf visits, slowest lane of a wave 150 on the 10k-sphere
-// scene), so a wave that loads 64 paths and waits for the slowest runs at ~0.2 lane occupancy.
-// Here a wave is persistent: whenever fewer than p.dynamic_fetch of its lanes are still traversing,
-// the finished lanes shade and store their paths and fetch new ones from the sub-queue (one
-// atomic on the sub-queue's fetch cursor per refill), while the others keep their traversal
+// steps for every ray (mean 16 node and leaf visits, slowest lane of a wave above 100 on the
+// 10k-sphere scene), so a wave that loads 64 paths and waits for the slowest runs at ~0.2 lane
+// occupancy.  Here a wave is persistent: whenever fewer than p.dynamic_fetch of its lanes are still
+// traversing, the finished lanes shade and store their paths and fetch new ones from the sub-queue
+// (one atomic on the sub-queue's fetch cursor per refill), while the others keep their traversal
 // state in registers and their stacks in LDS.  Results do not depend on which lane traces which
 // path; only the order of the survivors in the next queue changes.
-
+//
+// WHOLE: one launch traces the batch's paths from camera ray to termination.  A lane whose path
+// goes on keeps it and starts the next bounce's traversal at once; only camera rays are fetched.
+// The per-path radiance buffer and the resolve kernel make that possible -- no lane owns a pixel.
+// No queue records move through memory (56 bytes written and read per path and bounce otherwise),
+// and one launch has one tail of last, longest traversals instead of one per bounce.
 //
 // Measured and dropped: the tree's inner nodes staged in LDS by one 1024-thread workgroup per CU
 // (4-byte stack entries, 130 KiB of LDS on the 10 007-sphere scene) -- 61.3 ms per 8 iterations
 // against 53.8 ms: four waves per SIMD instead of six cost more than the shorter fetches gain.
+template <bool WHOLE>
 __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const WavefrontParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -196,6 +202,8 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
     bool has = false, trav = false, over = false, exhausted = false;
     V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f), T = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
     uint32_t pix = 0, it_sub = 0;
+    int bounce = p.bounce;              // WHOLE: per lane
+    unsigned long long continued = 0;   // WHOLE: Intersect calls beyond the camera rays (wave-uniform)
     float tmax = PT_INF;
     int best = -1;
     BvhTraversal tr;
@@ -229,6 +237,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
                         d = camera_ray(p.cam, x, y, pix, it_sub >> 2, (int)sub, k0, k1);
                         T = mk(1.f, 1.f, 1.f);
                         L = mk(0.f, 0.f, 0.f);
+                        if (WHOLE) bounce = 0;
                         has = true;
                     }
                 } else {
@@ -273,8 +282,8 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
         bool cont = false;
         if (fin) {
             bool end = true;
-            int b = p.bounce;
-            record_hit(p, n_pix, pix, it_sub, best);
+            int b = WHOLE ? bounce : p.bounce;
+            record_hit(p, n_pix, pix, it_sub, b, best);
             if (best >= 0) end = shade_bounce(sc, p.scene.sph[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
             if (end) {
                 float *pr = p.path_radiance + batch_path_index(p, n_pix, pix, it_sub) * 3;
@@ -282,9 +291,18 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
             }
             cont = !end;
             has = false;
+            if (WHOLE && cont) {   // the same lane traces the path's next ray
+                bounce = b;
+                has = true;
+                tmax = PT_INF;
+                best = -1;
+                over = false;
+                trav = bvh_begin(B, o, d, tmax, best, tr);
+            }
         }
         const unsigned long long mask = __ballot(cont);
-        if (mask) {
+        if (WHOLE) continued += (unsigned long long)__popcll(mask);
+        if (!WHOLE && mask) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             const int leader = (int)__builtin_ctzll(mask);
@@ -301,6 +319,8 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
         }
         if (exhausted && !__any(has)) break;
     }
+    // the resolve kernel counts the camera rays (and, per bounce, the queue lengths: zero here)
+    if (WHOLE && p.ray_counter && continued && lane == 0) atomicAdd(p.ray_counter, continued);
 }
 
 // Folds the batch's path radiances into the frame buffer: per pixel, iteration by iteration,
@@ -388,7 +408,8 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
         if (per_cu < 1u) per_cu = 1u;
         uint32_t rows = (per_cu * (uint32_t)n_cus + kWfSubQueues - 1) / kWfSubQueues;
         const dim3 pgrid(kWfSubQueues, chunks < rows ? chunks : rows);
-        hipLaunchKernelGGL(wf_step_bvh_kernel, pgrid, block, lds, stream, p);
+        if (p.whole_paths) hipLaunchKernelGGL(wf_step_bvh_kernel<true>, pgrid, block, lds, stream, p);
+        else               hipLaunchKernelGGL(wf_step_bvh_kernel<false>, pgrid, block, lds, stream, p);
     } else if (bvh) hipLaunchKernelGGL((wf_step_kernel<true, true>), grid, block, lds, stream, p);
     else if (tiled) hipLaunchKernelGGL((wf_step_kernel<true, false>), grid, block, lds, stream, p);
     else            hipLaunchKernelGGL((wf_step_kernel<false, false>), grid, block, lds, stream, p);

@@ -196,10 +196,17 @@ int pt_set_kernel_variant(pt_handle h, int variant);
  *   PT_TUNE_BVH_STACK          entries of the per-lane traversal stack (0: the default, two per
  *                              tree level + 2; a ray that runs out is finished by the wave-wide
  *                              scan; reset by pt_init_scene)
- *   PT_TUNE_WAVEFRONT_BATCH    paths per wavefront batch in units of 2^20 (0: the default; 124 bytes
- *                              of queues and radiance per path; kept across variant changes) */
+ *   PT_TUNE_WAVEFRONT_BATCH    paths in flight of the wavefront variant in units of 2^20 (0: the
+ *                              default; kept across variant changes)
+ *   PT_TUNE_WAVEFRONT_WHOLE_PATHS  BVH scenes: 1: the persistent waves follow every path to its end
+ *                              in one launch per batch, without queues (12 instead of 124 bytes
+ *                              per path in flight, 6 % slower on the 10 007-sphere scene); 0
+ *                              (default): one launch per bounce over the queues, whole paths only
+ *                              when the memory limit has no room for one iteration's queues
+ *                              (kept across variant changes) */
 enum { PT_TUNE_REGEN_MIN_IDLE = 0, PT_TUNE_CAMERA_RAY_RING = 1, PT_TUNE_STEAL_UNIT = 2, PT_TUNE_ITERATION_RANGES = 3,
-       PT_TUNE_WAVEFRONT_REFILL = 4, PT_TUNE_BVH_NODE_STEPS = 5, PT_TUNE_BVH_STACK = 6, PT_TUNE_WAVEFRONT_BATCH = 7 };
+       PT_TUNE_WAVEFRONT_REFILL = 4, PT_TUNE_BVH_NODE_STEPS = 5, PT_TUNE_BVH_STACK = 6, PT_TUNE_WAVEFRONT_BATCH = 7,
+       PT_TUNE_WAVEFRONT_WHOLE_PATHS = 8 };
 int pt_debug_set_tuning(pt_handle h, int key, int value);
 /* Device memory held by the instance: bytes[0] = allocated now (scene, BVH, scratch pool,
  * tickets, wavefront queues, internal frame buffer); bytes[1] = what a pt_run_n of n_iterations

@@ -221,17 +221,24 @@ def test_visit_budget_does_not_change_results(pt, O, torch_cuda, budget):
 def test_wavefront_dynamic_fetch_and_auto_variant(pt, O, torch_cuda, size):
     """BVH scenes default to the queue-fed persistent waves (PT_VARIANT_AUTO); every way of
     scheduling paths onto lanes gives the same bits: forced megakernel, static chunks (101),
-    refill thresholds 2 and 64, the default."""
+    refill thresholds 2 and 64, the default, whole paths per launch."""
     rng = np.random.default_rng(31)
     mats = materials(pt, [(0, 0.0), (1, 0.9), (2, 1.33), (0, 0.0)])
     walls, lights = room(pt, (0, 40, -20), 60)
     sph = np.concatenate([walls, cloud(pt, rng, 2500, (0, 40, -20), 50, 0.4, 2.0, 4)])
     cam = pt.Camera([0, 45, 35], [0, 38, -20], [0, 1, 0], size[0], size[1], 0, 0, 60.0)
     imgs, rays = {}, {}
-    for variant in (pt.VARIANT_AUTO, 0, 100, 101, 102, 164):
+    for variant in (pt.VARIANT_AUTO, 0, 100, 101, 102, 164, "whole paths"):
         tr = pt.Pathtracer(cam, 8, 9)
         tr.Init(mats, sph, lights)
-        if variant != pt.VARIANT_AUTO:
+        if variant == "whole paths":    # the persistent waves follow every path to its end in one launch
+            tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, 1)
+            hits, rad, rgb, n = tr.DebugTrace(0, 0, size[0], min(size[1], 16), 3)
+            tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, 0)
+            hits0, rad0, rgb0, n0 = tr.DebugTrace(0, 0, size[0], min(size[1], 16), 3)
+            assert np.array_equal(hits, hits0) and rad.tobytes() == rad0.tobytes() and rgb.tobytes() == rgb0.tobytes() and n == n0
+            tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, 1)
+        elif variant != pt.VARIANT_AUTO:
             tr.SetKernelVariant(variant)
         tr.ResetCounters()
         imgs[variant] = render(torch_cuda, tr, 2, 3).cpu().numpy().tobytes()   # iterations 2..4

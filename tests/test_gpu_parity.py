@@ -713,7 +713,15 @@ def test_variants_tuning_and_memory_footprint(pt, torch_cuda):
     tr.Release()
     tr = pt.Pathtracer(cam, 8, 1)
     tr.Init(mats, sph, lights)
-    tr.SetMemoryLimit(124 * 256 * 128 * 4 - 1)                     # not even one iteration's queues
+    tr.SetMemoryLimit(124 * 256 * 128 * 4 - 1)                     # not even one iteration's queues:
+    now, nxt = tr.MemoryFootprint(2)                               # whole paths per launch, 12 bytes per path
+    assert 12 * paths <= nxt - now <= 12 * paths + 2**20
+    assert render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes() == ref
+    assert tr.MemoryFootprint(2) == (nxt, nxt)
+    tr.Release()
+    tr = pt.Pathtracer(cam, 8, 1)
+    tr.Init(mats, sph, lights)
+    tr.SetMemoryLimit(12 * 256 * 128 * 4 - 1)                      # nor one iteration's radiance
     now, nxt = tr.MemoryFootprint(2)
     assert nxt == now                                              # below 48 MiB: no scratch pool either
     assert render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes() == ref     # rendered by the BVH megakernel
@@ -739,4 +747,12 @@ def test_variants_tuning_and_memory_footprint(pt, torch_cuda):
     assert tr.MemoryFootprint(5) == (nxt, nxt)
     tr.SetTuning(pt.TUNE_WAVEFRONT_BATCH, 1)                       # 2^20 paths in flight: eight iterations, four per set
     assert render(torch_cuda, tr, 1, 5).cpu().numpy().tobytes() == ref5
+    tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, 1)                 # every path to its end in one launch
+    tr.ResetCounters()
+    assert render(torch_cuda, tr, 1, 5).cpu().numpy().tobytes() == ref5
+    rays = tr.RayCount()
+    tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, 0)
+    tr.ResetCounters()
+    assert render(torch_cuda, tr, 1, 5).cpu().numpy().tobytes() == ref5
+    assert tr.RayCount() == rays
     tr.Release()
