@@ -12,8 +12,13 @@
  * The rest of pathtracer.cu needs nvcc, cuRAND and OpenGL and cannot be built here, so the
  * two kernels' bodies (pathtracer.cu:62-75,80-110) are driven by the loop in ref_render().
  *
- * It only exists in the development container: the GPU box has no reference tree, and the
- * tests there use the golden vectors this harness produced (oracle/gen_golden.py).
+ * It can only be BUILT where the reference tree exists (the development container).  The built
+ * libraries (oracle/_ref/*.so: git-ignored, so never in the history, but not excluded from what
+ * is sent to the GPU box) travel with the tree like every other built library: on the GPU box
+ * bench.py times libpt_ref.so on the host cores as the cpu_baseline's `reference_host_build`
+ * leg -- the reference's CPU path beside the GPU number -- and nothing else there uses it.
+ * The tests there use the golden vectors this harness produced (oracle/gen_golden.py); no
+ * reference source and no text cut from it leaves the container.
  *
  * What is NOT the reference here, and why:
  *   - the random floats: the reference reads a cuRAND buffer seeded with time(NULL); the
@@ -45,7 +50,10 @@
 
 #define __device__
 #define __global__
-#define private public /* read Camera::pxX/pxY/firstRayDir for the camera fixture */
+/* Camera keeps pxX / pxY / firstRayDir and the view state private and has no accessors for them
+ * (camera.h:159-171); the camera fixtures compare exactly those members, so the one header is
+ * included with `private` spelled `public`.  Access control does not change layout or code. */
+#define private public
 #include "camera.h"
 #undef private
 #include "material.h"
