@@ -75,8 +75,8 @@ struct pt_context {
     hipStream_t wf_stream2;
     hipEvent_t wf_fork;
     uint32_t wf_target_mpaths;   // paths per wavefront batch in units of 2^20 (0: kWfTargetPaths)
-    int wf_whole_paths;          // BVH scenes with dynamic fetch: whole paths in one launch, no queues
-    bool wf_has_queues;          // the buffer sets include the path queues
+    int wf_whole_paths;          // BVH scenes with dynamic fetch, PT_TUNE_WAVEFRONT_WHOLE_PATHS: -1 chosen per render
+    int wf_n_queues;             // path queues per buffer set (0, 1 or 2)
     uint32_t wf_sub_capacity;   // paths per sub-queue the buffers were sized for
     uint64_t wf_capacity;       // paths per batch the buffers were sized for
     std::string error;
@@ -199,8 +199,8 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->wf_stream2 = nullptr;
     h->wf_fork = nullptr;
     h->wf_target_mpaths = 0;
-    h->wf_whole_paths = 0;
-    h->wf_has_queues = false;
+    h->wf_whole_paths = -1;
+    h->wf_n_queues = 0;
     h->wf_sub_capacity = 0;
     h->wf_capacity = 0;
 
@@ -307,7 +307,7 @@ static void free_wavefront(pt_context *h)
     }
     memset(h->wf_pipe, 0, sizeof h->wf_pipe);
     h->wf_sub_capacity = 0; h->wf_capacity = 0;
-    h->wf_has_queues = false;
+    h->wf_n_queues = 0;
 }
 
 int pt_destroy(pt_handle h)
@@ -603,7 +603,7 @@ int pt_debug_set_tuning(pt_handle h, int key, int value)
         h->wf_target_mpaths = (uint32_t)value;
         return PT_OK;
     case PT_TUNE_WAVEFRONT_WHOLE_PATHS:
-        if (value != 0 && value != 1) break;
+        if (value < -1 || value > 2) break;
         h->wf_whole_paths = value;
         return PT_OK;
     default:
@@ -616,7 +616,15 @@ static uint32_t div_up(uint32_t a, uint32_t b);
 static uint32_t auto_chunks(uint64_t tiles, uint32_t n_iterations);
 static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets);
 static bool takes_wavefront(const pt_context *h, uint64_t last_iteration);
-static bool wavefront_whole_paths(const pt_context *h);
+static int wavefront_whole_paths(const pt_context *h);
+// Slots per sub-queue for a batch of `iterations` iterations over a w x h rectangle: the batch is
+// dealt out in blocks of 256 paths, block k to sub-queue k % 64, and a sub-queue keeps its survivors.
+static uint64_t wavefront_sub_capacity(uint32_t w, uint32_t h, uint64_t iterations)
+{
+    const uint64_t blocks = ((uint64_t)w * h * 4 * iterations + 255) / 256;
+    return (blocks + kWfSubQueues - 1) / kWfSubQueues * 256;
+}
+static uint64_t wavefront_bytes_per_path(const pt_context *h);
 
 int pt_set_memory_limit(pt_handle h, uint64_t bytes)
 {
@@ -634,8 +642,8 @@ int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
     const uint64_t steal_now = h->d_steal ? kStealPoolBytes + kStealMaskBytes : 0;
     const uint64_t tickets_now = (uint64_t)h->tickets_capacity * sizeof(uint32_t);
     const uint64_t counts = (uint64_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
-    const uint64_t queue_bytes = 2 * (3 * sizeof(float4) + sizeof(uint2));
-    const uint64_t wf_set = (h->wf_has_queues ? (uint64_t)h->wf_sub_capacity * kWfSubQueues * queue_bytes : 0) +
+    const uint64_t queue_bytes = 3 * sizeof(float4) + sizeof(uint2);
+    const uint64_t wf_set = (uint64_t)h->wf_n_queues * h->wf_sub_capacity * kWfSubQueues * queue_bytes +
                             h->wf_capacity * 3 * sizeof(float) + counts;
     const uint64_t wf_now = ((h->wf_pipe[0].counts ? 1 : 0) + (h->wf_pipe[1].counts ? 1 : 0)) * wf_set;
     bytes[0] = fixed + steal_now + tickets_now + wf_now;
@@ -646,8 +654,9 @@ int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
     const uint32_t batch_it = n_iterations ? wavefront_batch_iterations(h, paths_per_it, n_iterations, &wf_sets) : 0;
     if (n_iterations && h->scene_ready && takes_wavefront(h, h->iteration + (uint64_t)n_iterations) && batch_it > 0) {
         const uint64_t capacity = paths_per_it * batch_it;
-        const uint64_t sub_cap = ((capacity + 255) / 256 + kWfSubQueues - 1) / kWfSubQueues * 256;
-        const uint64_t need = wf_sets * ((wavefront_whole_paths(h) ? 0 : sub_cap * kWfSubQueues * queue_bytes) + capacity * 3 * sizeof(float) + counts);
+        const uint64_t sub_cap = wavefront_sub_capacity(h->camera.width, h->camera.height, batch_it);
+        const uint64_t n_queues = (wavefront_bytes_per_path(h) - 3 * sizeof(float)) / queue_bytes;
+        const uint64_t need = wf_sets * (n_queues * sub_cap * kWfSubQueues * queue_bytes + capacity * 3 * sizeof(float) + counts);
         if (need > wf_next) wf_next = need;
     } else if (n_iterations && h->scene_ready && !h->wavefront && h->steal && !h->steal_alloc_failed &&
                (!h->memory_limit || kStealPoolBytes + kStealMaskBytes <= h->memory_limit)) {
@@ -704,33 +713,41 @@ static void fill_params(const pt_context *h, RenderParams &p)
 
 static uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// Device memory per path of a wavefront batch: two queues of 56-byte path records + the path's
-// radiance; without the queues (whole paths per launch) the radiance alone.
-static const uint64_t kWfBytesPerPath = 2 * (3 * sizeof(float4) + sizeof(uint2)) + 3 * sizeof(float);
-static const uint64_t kWfBytesPerWholePath = 3 * sizeof(float);
+// Device memory per path in flight of the wavefront variant: the path's radiance + two queues of
+// 56-byte path records (one launch per bounce), one queue (camera rays in a launch of their own,
+// then whole paths), or none (whole paths from the camera ray on).
+static const uint64_t kWfQueueRecord = 3 * sizeof(float4) + sizeof(uint2);
+static const uint64_t kWfBytesPerPath = 2 * kWfQueueRecord + 3 * sizeof(float);
 // Device memory the wavefront buffers are sized for by default (two sets together).
 // Measured on the 10 007-sphere scene, 1080p x 16 iterations, per-bounce launches: 16 Mi paths in
 // flight 111 ms, 32 Mi 97, 64 Mi 92.7, 128 Mi 90.8 -- every launch ends with a tail of its longest
 // traversals, and the fewer and larger the launches the less that costs.
 static const uint64_t kWfTargetBytes = (64ull << 20) * kWfBytesPerPath;
 
-// BVH scenes traced by the persistent waves: does one launch per batch follow every path to its
-// end (no queues, 12 bytes per path) instead of one launch per bounce (124 bytes per path)?
-// Measured on the 10 007-sphere scene, 1080p x 16 iterations: 98.5 ms against 92.7 ms -- the
-// per-bounce launches keep the coherent camera rays (a quarter of all rays, traced at twice the
-// rate of the others) in waves of their own.  So only on request, or when the memory limit has
-// no room for one iteration's queues.
-static bool wavefront_whole_paths(const pt_context *h)
+// BVH scenes traced by the persistent waves: how the bounces map to launches.
+//   0  one launch per bounce over the queues (124 bytes per path in flight)
+//   1  one launch per batch follows every path from its camera ray to its end (no queues, 12 bytes)
+//   2  the camera rays in a launch of their own, a second launch follows every surviving path from
+//      its first bounce to its end (one queue, 68 bytes)
+// Measured on the 10 007-sphere scene, 1080p x 16 iterations: mode 0 92.5 ms, mode 2 96.2, mode 1
+// 98.4.  Camera rays are coherent and trace at twice the rate of scattered rays as long as they
+// share waves with each other, and a queue keeps even the scattered rays in runs that started in
+// the same 64 pixels; a lane that keeps its path gives that up.  So: one launch per bounce unless
+// asked otherwise, and the leaner modes when the memory limit has no room for one iteration of the
+// fuller one.
+static int wavefront_whole_paths(const pt_context *h)
 {
-    if (h->wf_dynamic_fetch <= 0 || h->accel != PT_ACCEL_AUTO || h->bvh.n_nodes == 0) return false;
-    if (h->wf_whole_paths) return true;
+    if (h->wf_dynamic_fetch <= 0 || h->accel != PT_ACCEL_AUTO || h->bvh.n_nodes == 0) return 0;
+    if (h->wf_whole_paths >= 0) return h->wf_whole_paths;
     const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
-    return h->memory_limit && h->memory_limit / kWfBytesPerPath < paths_per_it;
+    if (!h->memory_limit || h->memory_limit / kWfBytesPerPath >= paths_per_it) return 0;
+    return h->memory_limit / (kWfQueueRecord + 3 * sizeof(float)) >= paths_per_it ? 2 : 1;
 }
 
 static uint64_t wavefront_bytes_per_path(const pt_context *h)
 {
-    return wavefront_whole_paths(h) ? kWfBytesPerWholePath : kWfBytesPerPath;
+    const int mode = wavefront_whole_paths(h);
+    return (mode == 1 ? 0 : mode == 2 ? 1 : 2) * kWfQueueRecord + 3 * sizeof(float);
 }
 
 // Iterations per wavefront batch of a frame with `paths_per_it` paths per iteration, within the
@@ -756,11 +773,9 @@ static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_p
 
 // `sets` sets of queues, per-path radiance and counters for batches of `capacity` paths (kept while
 // they suffice).  A failed allocation frees what was allocated and reports PT_ERR_NOMEM.
-static int ensure_wavefront(pt_context *h, uint64_t capacity, uint32_t sets, size_t *counts_bytes_out)
+static int ensure_wavefront(pt_context *h, uint64_t capacity, uint64_t sub_cap64, uint32_t sets, size_t *counts_bytes_out)
 {
-    const bool queues = !wavefront_whole_paths(h);
-    const uint64_t blocks = (capacity + 255) / 256;
-    const uint64_t sub_cap64 = (blocks + kWfSubQueues - 1) / kWfSubQueues * 256;
+    const int n_queues = (int)((wavefront_bytes_per_path(h) - 3 * sizeof(float)) / kWfQueueRecord);
     if (sub_cap64 > 0xffffff00ull) return fail(h, PT_ERR_INVALID, "wavefront variant: image too large");
     const uint32_t sub_cap = (uint32_t)sub_cap64;
     const size_t counts_bytes = (size_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
@@ -770,7 +785,7 @@ static int ensure_wavefront(pt_context *h, uint64_t capacity, uint32_t sets, siz
             hipEventCreateWithFlags(&h->wf_fork, hipEventDisableTiming) != hipSuccess)
             return fail(h, PT_ERR_DEVICE, "wavefront variant: cannot create the second stream");
     }
-    bool have = capacity <= h->wf_capacity && sub_cap <= h->wf_sub_capacity && (h->wf_has_queues || !queues);
+    bool have = capacity <= h->wf_capacity && sub_cap <= h->wf_sub_capacity && h->wf_n_queues >= n_queues;
     for (uint32_t k = 0; k < sets; ++k) have = have && h->wf_pipe[k].counts;
     if (!have) {
         PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -779,7 +794,7 @@ static int ensure_wavefront(pt_context *h, uint64_t capacity, uint32_t sets, siz
         bool ok = true;
         for (uint32_t k = 0; k < sets && ok; ++k) {
             pt_context::WfPipe &pipe = h->wf_pipe[k];
-            for (int i = 0; i < 2 && ok && queues; ++i) {
+            for (int i = 0; i < n_queues && ok; ++i) {
                 ok = hipMalloc((void **)&pipe.queue[i].a, slots * sizeof(float4)) == hipSuccess &&
                      hipMalloc((void **)&pipe.queue[i].b, slots * sizeof(float4)) == hipSuccess &&
                      hipMalloc((void **)&pipe.queue[i].c, slots * sizeof(float4)) == hipSuccess &&
@@ -797,7 +812,7 @@ static int ensure_wavefront(pt_context *h, uint64_t capacity, uint32_t sets, siz
         }
         h->wf_capacity = capacity;
         h->wf_sub_capacity = sub_cap;
-        h->wf_has_queues = queues;
+        h->wf_n_queues = n_queues;
     }
     return PT_OK;
 }
@@ -811,7 +826,6 @@ static void fill_wavefront(const pt_context *h, WavefrontParams &p)
     p.max_bounces = h->max_bounces;
     p.dynamic_fetch = h->wf_dynamic_fetch;
     p.sub_capacity = h->wf_sub_capacity;
-    p.whole_paths = wavefront_whole_paths(h) ? 1 : 0;
     p.x0 = 0; p.y0 = 0; p.rect_w = p.cam.width; p.rect_h = p.cam.height;
 }
 
@@ -826,9 +840,12 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, size_t coun
     p.counts = pipe.counts;
     p.path_radiance = pipe.radiance;
     PT_HIP(h, hipMemsetAsync(pipe.counts, 0, counts_bytes, stream));
-    for (int b = 0; b <= (p.whole_paths ? 0 : h->max_bounces); ++b) {
+    const int mode = wavefront_whole_paths(h);
+    const int last = mode == 1 ? 0 : mode == 2 ? (h->max_bounces < 1 ? h->max_bounces : 1) : h->max_bounces;
+    for (int b = 0; b <= last; ++b) {
         p.bounce = b;
-        p.out = pipe.queue[b & 1];
+        p.whole_paths = mode == 1 || (mode == 2 && b == 1);
+        p.out = pipe.queue[b & 1];          // not written by a whole-path launch
         p.in = pipe.queue[(b & 1) ^ 1];
         PT_HIP(h, launch_wavefront_step(p, tiled, stream));
     }
@@ -852,7 +869,8 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
         return fail(h, PT_ERR_NOMEM, "wavefront variant: one iteration needs %llu MiB of queues, the memory limit is %llu MiB",
                     (unsigned long long)(paths_per_it * wavefront_bytes_per_path(h) >> 20), (unsigned long long)(h->memory_limit >> 20));
     size_t counts_bytes = 0;
-    const int rc = ensure_wavefront(h, paths_per_it * batch_it, sets, &counts_bytes);
+    const int rc = ensure_wavefront(h, paths_per_it * batch_it, wavefront_sub_capacity(h->camera.width, h->camera.height, batch_it),
+                                    sets, &counts_bytes);
     if (rc != PT_OK) return rc;
 
     WavefrontParams p;
@@ -1220,7 +1238,7 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
     // wavefront launches, the work-stealing megakernel, or the plain one.
     if (takes_wavefront(h, iteration) && h->integrator == PT_INTEGRATOR_PATH && iteration < (1u << 30)) {
         size_t counts_bytes = 0;
-        rc = ensure_wavefront(h, n_paths, 1, &counts_bytes);
+        rc = ensure_wavefront(h, n_paths, wavefront_sub_capacity(x1 - x0, y1 - y0, 1), 1, &counts_bytes);
         if (rc != PT_OK) goto cleanup;
         WavefrontParams p;
         fill_wavefront(h, p);

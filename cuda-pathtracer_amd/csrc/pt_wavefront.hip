@@ -160,8 +160,9 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
 // state in registers and their stacks in LDS.  Results do not depend on which lane traces which
 // path; only the order of the survivors in the next queue changes.
 //
-// WHOLE: one launch traces the batch's paths from camera ray to termination.  A lane whose path
-// goes on keeps it and starts the next bounce's traversal at once; only camera rays are fetched.
+// WHOLE: the launch follows the paths it fetches (camera rays, or the survivors of bounce
+// p.bounce - 1) to their end.  A lane whose path goes on keeps it and starts the next bounce's
+// traversal at once; nothing is appended to a queue.
 // The per-path radiance buffer and the resolve kernel make that possible -- no lane owns a pixel.
 // No queue records move through memory (56 bytes written and read per path and bounce otherwise),
 // and one launch has one tail of last, longest traversals instead of one per bounce.
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
     const uint64_t n_paths = (uint64_t)p.n_iterations * n_pix * 4;
 
     // items of this sub-queue: item j is slot j of the input queue, or at bounce 0 path
-    // ((j / 256) * 64 + q) * 256 + j % 256 of the batch (the static kernel's assignment)
+    // ((j / 256) * 64 + q) * 256 + j % 256 of the batch (the static kernel's assignment: a block of
+    // 256 paths is 64 pixels of an image row; 8x8-pixel tiles instead measured 4 % slower)
     uint32_t n_items;
     if (p.bounce == 0) {
         const uint64_t blocks = (n_paths + kBlockThreads - 1) / kBlockThreads;
@@ -237,7 +239,6 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
                         d = camera_ray(p.cam, x, y, pix, it_sub >> 2, (int)sub, k0, k1);
                         T = mk(1.f, 1.f, 1.f);
                         L = mk(0.f, 0.f, 0.f);
-                        if (WHOLE) bounce = 0;
                         has = true;
                     }
                 } else {
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
                     has = true;
                 }
                 if (has) {
+                    if (WHOLE) bounce = p.bounce;
                     tmax = PT_INF;
                     best = -1;
                     over = false;

@@ -198,12 +198,14 @@ int pt_set_kernel_variant(pt_handle h, int variant);
  *                              scan; reset by pt_init_scene)
  *   PT_TUNE_WAVEFRONT_BATCH    paths in flight of the wavefront variant in units of 2^20 (0: the
  *                              default; kept across variant changes)
- *   PT_TUNE_WAVEFRONT_WHOLE_PATHS  BVH scenes: 1: the persistent waves follow every path to its end
- *                              in one launch per batch, without queues (12 instead of 124 bytes
- *                              per path in flight, 6 % slower on the 10 007-sphere scene); 0
- *                              (default): one launch per bounce over the queues, whole paths only
- *                              when the memory limit has no room for one iteration's queues
- *                              (kept across variant changes) */
+ *   PT_TUNE_WAVEFRONT_WHOLE_PATHS  BVH scenes, how bounces map to launches: 0: one launch per
+ *                              bounce over two queues (124 bytes per path in flight); 2: the
+ *                              camera rays in a launch of their own, then one launch that follows
+ *                              every surviving path to its end (one queue, 68 bytes; 4 % slower on
+ *                              the 10 007-sphere scene); 1: one launch follows every path from its
+ *                              camera ray on (no queue, 12 bytes; 6 % slower); -1 (default): 0, or
+ *                              the fullest of 2 and 1 whose buffers for one iteration fit the
+ *                              memory limit (kept across variant changes) */
 enum { PT_TUNE_REGEN_MIN_IDLE = 0, PT_TUNE_CAMERA_RAY_RING = 1, PT_TUNE_STEAL_UNIT = 2, PT_TUNE_ITERATION_RANGES = 3,
        PT_TUNE_WAVEFRONT_REFILL = 4, PT_TUNE_BVH_NODE_STEPS = 5, PT_TUNE_BVH_STACK = 6, PT_TUNE_WAVEFRONT_BATCH = 7,
        PT_TUNE_WAVEFRONT_WHOLE_PATHS = 8 };

@@ -228,16 +228,19 @@ def test_wavefront_dynamic_fetch_and_auto_variant(pt, O, torch_cuda, size):
     sph = np.concatenate([walls, cloud(pt, rng, 2500, (0, 40, -20), 50, 0.4, 2.0, 4)])
     cam = pt.Camera([0, 45, 35], [0, 38, -20], [0, 1, 0], size[0], size[1], 0, 0, 60.0)
     imgs, rays = {}, {}
-    for variant in (pt.VARIANT_AUTO, 0, 100, 101, 102, 164, "whole paths"):
+    for variant in (pt.VARIANT_AUTO, 0, 100, 101, 102, 164, "whole paths 1", "whole paths 2"):
         tr = pt.Pathtracer(cam, 8, 9)
         tr.Init(mats, sph, lights)
-        if variant == "whole paths":    # the persistent waves follow every path to its end in one launch
-            tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, 1)
+        if str(variant).startswith("whole paths"):
+            # the persistent waves follow every path to its end: from the camera ray on (1), or
+            # from the first bounce on after a launch for the camera rays (2)
+            mode = int(variant[-1])
+            tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, mode)
             hits, rad, rgb, n = tr.DebugTrace(0, 0, size[0], min(size[1], 16), 3)
             tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, 0)
             hits0, rad0, rgb0, n0 = tr.DebugTrace(0, 0, size[0], min(size[1], 16), 3)
             assert np.array_equal(hits, hits0) and rad.tobytes() == rad0.tobytes() and rgb.tobytes() == rgb0.tobytes() and n == n0
-            tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, 1)
+            tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, mode)
         elif variant != pt.VARIANT_AUTO:
             tr.SetKernelVariant(variant)
         tr.ResetCounters()

@@ -713,8 +713,17 @@ def test_variants_tuning_and_memory_footprint(pt, torch_cuda):
     tr.Release()
     tr = pt.Pathtracer(cam, 8, 1)
     tr.Init(mats, sph, lights)
-    tr.SetMemoryLimit(124 * 256 * 128 * 4 - 1)                     # not even one iteration's queues:
-    now, nxt = tr.MemoryFootprint(2)                               # whole paths per launch, 12 bytes per path
+    ppi = 256 * 128 * 4
+    tr.SetMemoryLimit(124 * ppi - 1)                               # no room for one iteration's two queues:
+    now, nxt = tr.MemoryFootprint(2)                               # camera rays, then whole paths; one queue, 68 bytes
+    assert 68 * ppi <= nxt - now <= 68 * ppi + 2**20               # one iteration per batch
+    assert render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes() == ref
+    assert tr.MemoryFootprint(2) == (nxt, nxt)
+    tr.Release()
+    tr = pt.Pathtracer(cam, 8, 1)
+    tr.Init(mats, sph, lights)
+    tr.SetMemoryLimit(68 * ppi - 1)                                # nor for one queue: whole paths from the camera ray on,
+    now, nxt = tr.MemoryFootprint(2)                               # 12 bytes per path, both iterations in one batch
     assert 12 * paths <= nxt - now <= 12 * paths + 2**20
     assert render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes() == ref
     assert tr.MemoryFootprint(2) == (nxt, nxt)
@@ -747,12 +756,11 @@ def test_variants_tuning_and_memory_footprint(pt, torch_cuda):
     assert tr.MemoryFootprint(5) == (nxt, nxt)
     tr.SetTuning(pt.TUNE_WAVEFRONT_BATCH, 1)                       # 2^20 paths in flight: eight iterations, four per set
     assert render(torch_cuda, tr, 1, 5).cpu().numpy().tobytes() == ref5
-    tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, 1)                 # every path to its end in one launch
-    tr.ResetCounters()
-    assert render(torch_cuda, tr, 1, 5).cpu().numpy().tobytes() == ref5
-    rays = tr.RayCount()
-    tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, 0)
-    tr.ResetCounters()
-    assert render(torch_cuda, tr, 1, 5).cpu().numpy().tobytes() == ref5
-    assert tr.RayCount() == rays
+    rays = []
+    for mode in (1, 2, 0):                                         # every path to its end in one launch; from the
+        tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, mode)          # first bounce on; one launch per bounce
+        tr.ResetCounters()
+        assert render(torch_cuda, tr, 1, 5).cpu().numpy().tobytes() == ref5
+        rays.append(tr.RayCount())
+    assert rays[0] == rays[1] == rays[2]
     tr.Release()
