@@ -290,3 +290,37 @@ def test_small_scenes_have_no_bvh(pt, torch_cuda):
     with pytest.raises(pt.PtError):
         tr.SetAccel(7)
     tr.Release()
+
+
+def test_two_buffer_sets_respect_the_callers_stream(pt, torch_cuda):
+    """A render of several wavefront batches alternates between two buffer sets on the caller's
+    stream and a stream of the instance; work the caller enqueues on its stream before and after
+    an asynchronous pt_run_n is ordered against all of it: the frame is cleared by a kernel on the
+    caller's stream just before, and copied by one just after, without any host synchronisation."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    mats = materials(pt, [(0, 0.0), (1, 0.9), (2, 1.33), (0, 0.0)])
+    walls, lights = room(pt, (0, 40, -20), 60)
+    sph = np.concatenate([walls, cloud(pt, rng, 1200, (0, 40, -20), 50, 0.5, 2.5, 4)])
+    cam = pt.Camera([0, 45, 35], [0, 38, -20], [0, 1, 0], 320, 200, 0, 0, 60.0)
+    tr = pt.Pathtracer(cam, 6, 3)
+    tr.Init(mats, sph, lights)
+    ref = render(torch, tr, 1, 7).cpu().numpy().tobytes()          # one batch, default stream
+    tr.Release()
+    tr = pt.Pathtracer(cam, 6, 3)
+    tr.Init(mats, sph, lights)
+    tr.SetMemoryLimit(2 * 124 * 320 * 200 * 4 + 2**20)             # two sets of one iteration each: seven batches
+    side = torch.cuda.Stream()
+    tr.SetStream(side.cuda_stream)
+    buf = torch.full((320 * 200 * 3,), 123.0, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for rep in range(3):
+            buf.fill_(float("nan"))                               # iteration 1 overwrites whatever is there
+            tr.Reset()
+            tr.RunN(buf, 7, sync=False)
+            out = buf.clone()                                     # on the caller's stream, behind both sets
+    side.synchronize()
+    assert out.cpu().numpy().tobytes() == ref
+    assert buf.cpu().numpy().tobytes() == ref
+    tr.Release()
