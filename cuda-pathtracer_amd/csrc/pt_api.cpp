@@ -280,8 +280,9 @@ static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sp
     // difference between 10 and 20 entries, 8 costs 15 %.  A ray that does run out gives up the
     // tree and is finished by the wave-wide scan.
     h->bvh.depth = std::min(std::min(2 * d.depth + 2, 3 * d.depth), 12u);
-    // A wave-wide scan of n spheres costs about as much as n / 80 divergent box visits.
-    h->bvh_default_budget = n / 80 > 64 ? n / 80 : 64;
+    // A wave-wide scan of n spheres costs about as much as n / 40 divergent visits of four-wide
+    // nodes (10 007 spheres, ms per 16 iterations: budget 64 101, 90 93.9, 125 92.6, 180 91.4, 250 91.0, 400 91.4).
+    h->bvh_default_budget = n / 40 > 64 ? n / 40 : 64;
     h->bvh.budget = h->bvh_default_budget;
     h->bvh.node_steps = 2;   // measured on the 10 007-sphere scene: 1: 70.5, 2: 68.8, 3: 70.6, 4: 74.4 ms per 8 iterations
     h->bvh_default_stack = h->bvh.depth;

@@ -244,7 +244,7 @@ int pt_set_accel(pt_handle h, int mode);
 uint32_t pt_accel_nodes(pt_handle h);
 /* A ray that has visited more than `visits` boxes and leaves stops descending and is finished
  * by its whole wave scanning all spheres (same result; bounds the cost of the few rays whose
- * boxes must be widened enormously).  0 restores the default, max(64, spheres / 80), set by
+ * boxes must be widened enormously).  0 restores the default, max(64, spheres / 40), set by
  * pt_init_scene.  A tuning and test knob. */
 int pt_set_accel_budget(pt_handle h, uint32_t visits);
 /* Test hook, host only (no device needed): builds the BVH pt_init_scene would build for these
