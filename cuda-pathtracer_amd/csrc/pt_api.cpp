@@ -300,7 +300,6 @@ static void free_wavefront(pt_context *h)
             if (q.a) (void)hipFree(q.a);
             if (q.b) (void)hipFree(q.b);
             if (q.c) (void)hipFree(q.c);
-            if (q.path) (void)hipFree(q.path);
         }
         if (pipe.radiance) (void)hipFree(pipe.radiance);
         if (pipe.counts) (void)hipFree(pipe.counts);
@@ -643,7 +642,7 @@ int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
     const uint64_t steal_now = h->d_steal ? kStealPoolBytes + kStealMaskBytes : 0;
     const uint64_t tickets_now = (uint64_t)h->tickets_capacity * sizeof(uint32_t);
     const uint64_t counts = (uint64_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
-    const uint64_t queue_bytes = 3 * sizeof(float4) + sizeof(uint2);
+    const uint64_t queue_bytes = 2 * sizeof(float4) + sizeof(WavefrontTail);
     const uint64_t wf_set = (uint64_t)h->wf_n_queues * h->wf_sub_capacity * kWfSubQueues * queue_bytes +
                             h->wf_capacity * 3 * sizeof(float) + counts;
     const uint64_t wf_now = ((h->wf_pipe[0].counts ? 1 : 0) + (h->wf_pipe[1].counts ? 1 : 0)) * wf_set;
@@ -715,9 +714,9 @@ static void fill_params(const pt_context *h, RenderParams &p)
 static uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // Device memory per path in flight of the wavefront variant: the path's radiance + two queues of
-// 56-byte path records (one launch per bounce), one queue (camera rays in a launch of their own,
+// 44-byte path records (one launch per bounce), one queue (camera rays in a launch of their own,
 // then whole paths), or none (whole paths from the camera ray on).
-static const uint64_t kWfQueueRecord = 3 * sizeof(float4) + sizeof(uint2);
+static const uint64_t kWfQueueRecord = 2 * sizeof(float4) + sizeof(WavefrontTail);
 static const uint64_t kWfBytesPerPath = 2 * kWfQueueRecord + 3 * sizeof(float);
 // Device memory the wavefront buffers are sized for by default (two sets together).
 // Measured on the 10 007-sphere scene, 1080p x 16 iterations, per-bounce launches: 16 Mi paths in
@@ -726,10 +725,10 @@ static const uint64_t kWfBytesPerPath = 2 * kWfQueueRecord + 3 * sizeof(float);
 static const uint64_t kWfTargetBytes = (64ull << 20) * kWfBytesPerPath;
 
 // BVH scenes traced by the persistent waves: how the bounces map to launches.
-//   0  one launch per bounce over the queues (124 bytes per path in flight)
+//   0  one launch per bounce over the queues (100 bytes per path in flight)
 //   1  one launch per batch follows every path from its camera ray to its end (no queues, 12 bytes)
 //   2  the camera rays in a launch of their own, a second launch follows every surviving path from
-//      its first bounce to its end (one queue, 68 bytes)
+//      its first bounce to its end (one queue, 56 bytes)
 // Measured on the 10 007-sphere scene, 1080p x 16 iterations: mode 0 92.5 ms, mode 2 96.2, mode 1
 // 98.4.  Camera rays are coherent and trace at twice the rate of scattered rays as long as they
 // share waves with each other, and a queue keeps even the scattered rays in runs that started in
@@ -798,8 +797,7 @@ static int ensure_wavefront(pt_context *h, uint64_t capacity, uint64_t sub_cap64
             for (int i = 0; i < n_queues && ok; ++i) {
                 ok = hipMalloc((void **)&pipe.queue[i].a, slots * sizeof(float4)) == hipSuccess &&
                      hipMalloc((void **)&pipe.queue[i].b, slots * sizeof(float4)) == hipSuccess &&
-                     hipMalloc((void **)&pipe.queue[i].c, slots * sizeof(float4)) == hipSuccess &&
-                     hipMalloc((void **)&pipe.queue[i].path, slots * sizeof(uint2)) == hipSuccess;
+                     hipMalloc((void **)&pipe.queue[i].c, slots * sizeof(WavefrontTail)) == hipSuccess;
             }
             ok = ok && hipMalloc((void **)&pipe.radiance, capacity * 3 * sizeof(float)) == hipSuccess &&
                  hipMalloc((void **)&pipe.counts, counts_bytes) == hipSuccess &&
@@ -841,6 +839,8 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, size_t coun
     p.counts = pipe.counts;
     p.path_radiance = pipe.radiance;
     PT_HIP(h, hipMemsetAsync(pipe.counts, 0, counts_bytes, stream));
+    const uint64_t batch_paths = (uint64_t)p.n_iterations * p.rect_w * p.rect_h * 4;
+    PT_HIP(h, hipMemsetAsync(pipe.radiance, 0, batch_paths * 3 * sizeof(float), stream));
     const int mode = wavefront_whole_paths(h);
     const int last = mode == 1 ? 0 : mode == 2 ? (h->max_bounces < 1 ? h->max_bounces : 1) : h->max_bounces;
     for (int b = 0; b <= last; ++b) {

@@ -144,16 +144,19 @@ hipError_t launch_render_nee(const RenderParams &p, uint32_t grid_x, uint32_t gr
 
 // ---- wavefront (path-compaction) variant ------------------------------------------------------
 // A batch holds n_iterations x width x height x 4 paths.  Every bounce is one kernel launch over
-// a compacted queue of live paths in device memory; finished paths leave their radiance in
-// `path_radiance`, which wf_resolve folds into the frame buffer in the reference's order.
+// a compacted queue of live paths in device memory; the emission a path collects is added to its
+// entry of `path_radiance` (zeroed per batch) bounce by bounce, in the order the reference adds it
+// to L, and wf_resolve folds the entries into the frame buffer in the reference's order.
 constexpr uint32_t kWfSubQueues = 64;     // independent sub-queues (one compaction counter each)
 constexpr uint32_t kWfCountStride = 32;   // uint32 per counter: every counter on its own 128-B line
 
+// Path record of the queues, 44 bytes in three arrays.  The path's radiance is not carried: a
+// bounce that meets a light adds its contribution to the path's entry of `path_radiance`.
+struct WavefrontTail { float tz; uint32_t pix, it_sub; };   // (Tz, pixel index, iteration << 2 | sub-sample)
 struct WavefrontQueue {   // [kWfSubQueues][sub_capacity]
-    float4 *a;        // (ox, oy, oz, dx)
-    float4 *b;        // (dy, dz, Tx, Ty)
-    float4 *c;        // (Tz, Lx, Ly, Lz)
-    uint2 *path;      // (pixel index, iteration << 2 | sub-sample)
+    float4 *a;            // (ox, oy, oz, dx)
+    float4 *b;            // (dy, dz, Tx, Ty)
+    WavefrontTail *c;
 };
 
 struct WavefrontParams {
@@ -173,7 +176,7 @@ struct WavefrontParams {
     uint32_t *counts;           // [max_bounces + 2][kWfSubQueues][kWfCountStride]: word 0 = paths alive
                                 // in sub-queue q entering bounce k, word 1 = fetch cursor of the
                                 // dynamic-fetch kernel over those paths
-    float *path_radiance;       // [paths][3]
+    float *path_radiance;       // [paths][3], zero when the batch starts
     // resolve
     int accum_mode, overwrite;
     float *buffer;              // may be NULL (parity hook)

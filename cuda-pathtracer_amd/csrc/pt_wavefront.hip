@@ -3,9 +3,9 @@
 // The megakernel (pt_kernels.hip) keeps a path in one lane from camera ray to termination.
 // Here every bounce is its own launch over a compacted queue of live paths in device memory:
 // each launch reads a path's state, runs one Intersect + one bounce of shading (the same device
-// functions as the megakernel, so results are bit-identical) and either stores the path's final
-// radiance or appends the continued path to the next queue.  All lanes of a wave start every
-// launch alive and at the same bounce; the price is ~112 B of queue traffic per path-bounce
+// functions as the megakernel, so results are bit-identical), adds what the bounce collected to
+// the path's radiance and appends the path to the next queue if it goes on.  All lanes of a wave start every
+// launch alive and at the same bounce; the price is ~88 B of queue traffic per path-bounce
 // and one launch per bounce.  pt_set_kernel_variant(h, PT_VARIANT_WAVEFRONT) selects it; which
 // variant is faster depends on the scene (see the profiles).
 //
@@ -56,6 +56,18 @@ PT_DEV void record_hit(const WavefrontParams &p, uint32_t n_pix, uint32_t pix, u
     if (p.hit_ids) p.hit_ids[batch_path_index(p, n_pix, pix, it_sub) * (size_t)(p.max_bounces + 1) + bounce] = best;
 }
 
+// Adds the emission a bounce collected to the path's radiance and clears it.  The entry starts
+// at zero and takes the terms in bounce order, one launch (or one lane) after the other: the sum
+// ((0 + e1) + e2) + ... is the one Trace builds in L (pathtracer.cu:136).
+PT_DEV void bank_radiance(const WavefrontParams &p, uint32_t n_pix, uint32_t pix, uint32_t it_sub, V3 &L)
+{
+    if (L.x != 0.f || L.y != 0.f || L.z != 0.f) {
+        float *pr = p.path_radiance + batch_path_index(p, n_pix, pix, it_sub) * 3;
+        pr[0] += L.x; pr[1] += L.y; pr[2] += L.z;
+        L = mk(0.f, 0.f, 0.f);
+    }
+}
+
 template <bool TILED, bool BVH>
 __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontParams p)
 {
@@ -104,10 +116,10 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
             active = slot_in < n_items;
             if (active) {
                 const size_t s = (size_t)q * p.sub_capacity + slot_in;
-                const float4 a = p.in.a[s], bb = p.in.b[s], c = p.in.c[s];
-                const uint2 id = p.in.path[s];
-                o = mk(a.x, a.y, a.z); d = mk(a.w, bb.x, bb.y); T = mk(bb.z, bb.w, c.x); L = mk(c.y, c.z, c.w);
-                pix = id.x; it_sub = id.y;
+                const float4 a = p.in.a[s], bb = p.in.b[s];
+                const WavefrontTail c = p.in.c[s];
+                o = mk(a.x, a.y, a.z); d = mk(a.w, bb.x, bb.y); T = mk(bb.z, bb.w, c.tz);
+                pix = c.pix; it_sub = c.it_sub;
             }
         }
 
@@ -123,10 +135,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
             if (best >= 0) {
                 const float4 s = TILED ? p.scene.sph[best] : sc.sph[best];
                 end = shade_bounce(sc, s, best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
-            }
-            if (end) {
-                float *pr = p.path_radiance + batch_path_index(p, n_pix, pix, it_sub) * 3;
-                pr[0] = L.x; pr[1] = L.y; pr[2] = L.z;
+                bank_radiance(p, n_pix, pix, it_sub, L);
             }
             cont = !end;
         }
@@ -144,8 +153,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
                 const size_t s = (size_t)q * p.sub_capacity + base + rank;
                 p.out.a[s] = make_float4(o.x, o.y, o.z, d.x);
                 p.out.b[s] = make_float4(d.y, d.z, T.x, T.y);
-                p.out.c[s] = make_float4(T.z, L.x, L.y, L.z);
-                p.out.path[s] = make_uint2(pix, it_sub);
+                p.out.c[s] = WavefrontTail{T.z, pix, it_sub};
             }
         }
     }
@@ -243,10 +251,11 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
                     }
                 } else {
                     const size_t s = (size_t)q * p.sub_capacity + j;
-                    const float4 a = p.in.a[s], bb = p.in.b[s], c = p.in.c[s];
-                    const uint2 id = p.in.path[s];
-                    o = mk(a.x, a.y, a.z); d = mk(a.w, bb.x, bb.y); T = mk(bb.z, bb.w, c.x); L = mk(c.y, c.z, c.w);
-                    pix = id.x; it_sub = id.y;
+                    const float4 a = p.in.a[s], bb = p.in.b[s];
+                    const WavefrontTail c = p.in.c[s];
+                    o = mk(a.x, a.y, a.z); d = mk(a.w, bb.x, bb.y); T = mk(bb.z, bb.w, c.tz);
+                    L = mk(0.f, 0.f, 0.f);
+                    pix = c.pix; it_sub = c.it_sub;
                     has = true;
                 }
                 if (has) {
@@ -286,10 +295,9 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
             bool end = true;
             int b = WHOLE ? bounce : p.bounce;
             record_hit(p, n_pix, pix, it_sub, b, best);
-            if (best >= 0) end = shade_bounce(sc, p.scene.sph[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
-            if (end) {
-                float *pr = p.path_radiance + batch_path_index(p, n_pix, pix, it_sub) * 3;
-                pr[0] = L.x; pr[1] = L.y; pr[2] = L.z;
+            if (best >= 0) {
+                end = shade_bounce(sc, p.scene.sph[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
+                bank_radiance(p, n_pix, pix, it_sub, L);
             }
             cont = !end;
             has = false;
@@ -315,8 +323,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
                 const size_t s = (size_t)q * p.sub_capacity + base + rank;
                 p.out.a[s] = make_float4(o.x, o.y, o.z, d.x);
                 p.out.b[s] = make_float4(d.y, d.z, T.x, T.y);
-                p.out.c[s] = make_float4(T.z, L.x, L.y, L.z);
-                p.out.path[s] = make_uint2(pix, it_sub);
+                p.out.c[s] = WavefrontTail{T.z, pix, it_sub};
             }
         }
         if (exhausted && !__any(has)) break;

@@ -170,7 +170,7 @@ int pt_reset_counters(pt_handle h);
  *   PT_VARIANT_REGENERATION: megakernel, persistent lanes with path regeneration
  *   PT_VARIANT_CLASSIC: megakernel, a wave starts new paths only when all its lanes are idle
  *   PT_VARIANT_WAVEFRONT: one launch per bounce over compacted path queues in device memory
- *     (124 bytes per path in flight, up to about 8 GiB, allocated on first use -- see
+ *     (100 bytes per path in flight, up to about 6.7 GB, allocated on first use -- see
  *     pt_memory_footprint and pt_set_memory_limit; no row bands).  A render of more iterations
  *     than fit runs as batches that alternate between two buffer sets on two streams (the
  *     caller's and one of the instance's), so that one batch's launches fill the chip while the
@@ -199,9 +199,9 @@ int pt_set_kernel_variant(pt_handle h, int variant);
  *   PT_TUNE_WAVEFRONT_BATCH    paths in flight of the wavefront variant in units of 2^20 (0: the
  *                              default; kept across variant changes)
  *   PT_TUNE_WAVEFRONT_WHOLE_PATHS  BVH scenes, how bounces map to launches: 0: one launch per
- *                              bounce over two queues (124 bytes per path in flight); 2: the
+ *                              bounce over two queues (100 bytes per path in flight); 2: the
  *                              camera rays in a launch of their own, then one launch that follows
- *                              every surviving path to its end (one queue, 68 bytes; 4 % slower on
+ *                              every surviving path to its end (one queue, 56 bytes; 4 % slower on
  *                              the 10 007-sphere scene); 1: one launch follows every path from its
  *                              camera ray on (no queue, 12 bytes; 6 % slower); -1 (default): 0, or
  *                              the fullest of 2 and 1 whose buffers for one iteration fit the

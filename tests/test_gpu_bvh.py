@@ -309,7 +309,7 @@ def test_two_buffer_sets_respect_the_callers_stream(pt, torch_cuda):
     tr.Release()
     tr = pt.Pathtracer(cam, 6, 3)
     tr.Init(mats, sph, lights)
-    tr.SetMemoryLimit(2 * 124 * 320 * 200 * 4 + 2**20)             # two sets of one iteration each: seven batches
+    tr.SetMemoryLimit(2 * 100 * 320 * 200 * 4 + 2**20)             # two sets of one iteration each: seven batches
     side = torch.cuda.Stream()
     tr.SetStream(side.cuda_stream)
     buf = torch.full((320 * 200 * 3,), 123.0, device="cuda")
