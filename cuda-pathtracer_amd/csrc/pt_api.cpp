@@ -286,7 +286,7 @@ static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sp
     h->bvh.budget = h->bvh_default_budget;
     h->bvh.node_steps = 2;   // measured on the 10 007-sphere scene: 1: 70.5, 2: 68.8, 3: 70.6, 4: 74.4 ms per 8 iterations
     h->bvh_default_stack = h->bvh.depth;
-    for (int a = 0; a < 3; ++a) { h->bvh.centre[a] = d.centre[a]; h->bvh.grid_origin[a] = d.grid_origin[a]; h->bvh.grid_step[a] = d.grid_step[a]; h->bvh.grid_inv_step[a] = 1.f / d.grid_step[a]; }
+    for (int a = 0; a < 3; ++a) { h->bvh.centre[a] = d.centre[a]; h->bvh.grid_origin[a] = d.grid_origin[a]; h->bvh.grid_step[a] = d.grid_step[a]; }
     h->bvh.half_diag = d.half_diag;
     h->bvh.r_min = d.r_min;
     return PT_OK;

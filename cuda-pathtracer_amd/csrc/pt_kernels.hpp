@@ -73,7 +73,7 @@ struct BvhParams {
     uint32_t node_steps;      // inner-node steps a wave takes per leaf step (the lanes of a wave alternate in lockstep)
     float centre[3];
     float half_diag, r_min;
-    float grid_origin[3], grid_step[3], grid_inv_step[3];   // plane = grid_origin + q * grid_step
+    float grid_origin[3], grid_step[3];   // plane = grid_origin + q * grid_step
     unsigned long long *stats;   // 32 counters, written only by -DPT_BVH_STATS builds
 };
 
