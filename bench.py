@@ -253,9 +253,7 @@ def main():
     tr.SetAccel(pt.ACCEL_AUTO if args.accel == "auto" else pt.ACCEL_BRUTE_FORCE)
     tr.SetIntegrator(pt.INTEGRATOR_NEE_MIS if args.integrator == "nee" else pt.INTEGRATOR_PATH)
     bvh = args.accel == "auto" and tr.AccelNodes() > 0
-    # what PT_VARIANT_AUTO resolves to (pt_set_kernel_variant in include/ptmi.h)
-    # linear-scan scenes render with the work-stealing megakernel, BVH scenes with the wavefront variant
-    eff_variant = args.variant if args.variant >= 0 else ((100 if bvh else 500) if args.integrator == "path" else 0)
+    # what PT_VARIANT_AUTO resolves to is asked of the library after the warm-up (pt_last_launch)
     tr.SetStream(torch.cuda.current_stream().cuda_stream)
     tile_split = grouped and args.split == "tile"
     if grouped and not tile_split:
@@ -377,7 +375,15 @@ def main():
     fpr = flops_per_ray_bvh(args.workload) if bvh else flops_per_ray(len(sph))
     # HBM bytes per step from the committed PMC passes of this same command (rocprofv3 cannot be
     # run from inside the benchmark): profiles/pmc_traffic_<workload>_v<variant>.json
-    tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}{'_bvh' if bvh else ''}_v{eff_variant}.json")
+    launch = tr.LastLaunch()
+    launch_tag, launch_kernel = {
+        pt.LAUNCH_MEGAKERNEL: ("v0", "render_kernel"),
+        pt.LAUNCH_MEGAKERNEL_STEALING: ("v500", "render_steal_kernel"),
+        pt.LAUNCH_WAVEFRONT: ("v100", "wf_step_* (all launches of a step)"),
+        pt.LAUNCH_WAVEFRONT_WHOLE_PATHS: ("v100whole", "wf_step_bvh_kernel<whole paths> (all launches of a step)"),
+        pt.LAUNCH_PATH_POOL: ("pool", "wf_pool_kernel"),
+    }.get(launch, ("none", "none"))
+    tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}{'_bvh' if bvh else ''}_{launch_tag}.json")
     pmc = pmc_summary(tpath) if args.integrator == "path" else {}
     traffic = pmc.get("hbm_bytes_per_step")
     achieved = rays_per_launch * fpr / (launch_ms * 1e-3) / 1e12 if fpr else None
@@ -399,7 +405,7 @@ def main():
                        "parallelism": "single" if world == 1 else
                                       f"{'tile (16-row bands)' if tile_split else 'sample-range'} split x{world} + "
                                       f"RCCL reduce(sum) overlapped with the next render",
-                       "kernel_variant": eff_variant,
+                       "kernel_variant": args.variant, "launch": launch_kernel,
                        "nearest_hit": "sphere BVH" if bvh else "linear scan", "integrator": args.integrator},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS if achieved else None,
@@ -412,9 +418,7 @@ def main():
                          "valu_issue_util": pmc.get("valu_issue_util"),
                          "active_lane_frac": pmc.get("active_lane_frac"),
                          "wait_frac": pmc.get("wait_frac"),
-                         "kernel": ("render_kernel" if eff_variant < 100 else
-                                    "render_steal_kernel" if eff_variant >= 500 else
-                                    "wf_step_* (all launches of a step)"),
+                         "kernel": launch_kernel,
                          "launch_ms": launch_ms,
                          "flops_per_bounce": fpr, "bounces_per_launch": rays_per_launch},
         }

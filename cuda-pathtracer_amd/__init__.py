@@ -42,8 +42,9 @@ SCENE_DEMO, SCENE_SYNTH10K, SCENE_MIXED = 0, 1, 2
 VARIANT_AUTO, VARIANT_REGENERATION, VARIANT_CLASSIC, VARIANT_WAVEFRONT, VARIANT_STEALING = -1, 0, 1, 100, 500
 ACCEL_AUTO, ACCEL_BRUTE_FORCE = 0, 1
 INTEGRATOR_PATH, INTEGRATOR_NEE_MIS = 0, 1
+LAUNCH_NONE, LAUNCH_MEGAKERNEL, LAUNCH_MEGAKERNEL_STEALING, LAUNCH_WAVEFRONT, LAUNCH_WAVEFRONT_WHOLE_PATHS, LAUNCH_PATH_POOL = range(6)
 TUNE_REGEN_MIN_IDLE, TUNE_CAMERA_RAY_RING, TUNE_STEAL_UNIT, TUNE_ITERATION_RANGES, TUNE_WAVEFRONT_REFILL = 0, 1, 2, 3, 4
-TUNE_BVH_NODE_STEPS, TUNE_BVH_STACK, TUNE_WAVEFRONT_BATCH, TUNE_WAVEFRONT_WHOLE_PATHS = 5, 6, 7, 8
+TUNE_BVH_NODE_STEPS, TUNE_BVH_STACK, TUNE_WAVEFRONT_BATCH, TUNE_WAVEFRONT_WHOLE_PATHS, TUNE_POOL_ITERATIONS = 5, 6, 7, 8, 9
 PT_OK, PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_DEVICE, PT_ERR_NOMEM = 0, -1, -2, -3, -4
 
 # Every symbol include/ptmi.h declares: (name, restype, argtypes)
@@ -80,6 +81,7 @@ ABI = [
     ("pt_lane_stats", _i32, [_vp, _pu64]),
     ("pt_debug_build_bvh", _i32, [_vp, _u32, _pu32, _vp, _vp, _vp]),
     ("pt_last_kernel_ms", _i32, [_vp, _pf]),
+    ("pt_last_launch", _i32, [_vp, ctypes.POINTER(ctypes.c_int)]),
     ("pt_read_image", _i32, [_vp, _vp, _vp]),
     ("pt_debug_trace", _i32, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _pu64]),
     ("pt_selftest_eval", _i32, [_vp, _i32, _vp, _vp, _vp, _u64]),
@@ -379,6 +381,12 @@ class Pathtracer:
         v = ctypes.c_float(0)
         self._check(self._lib.pt_last_kernel_ms(self._h, ctypes.byref(v)))
         return float(v.value)
+
+    def LastLaunch(self) -> int:
+        """LAUNCH_* of the last render: what PT_VARIANT_AUTO resolved to."""
+        v = ctypes.c_int(0)
+        self._check(self._lib.pt_last_launch(self._h, ctypes.byref(v)))
+        return int(v.value)
 
     def ReadImage(self, dev_buffer) -> np.ndarray:
         out = np.empty((self.height, self.width, 3), np.float32)

@@ -77,6 +77,8 @@ struct pt_context {
     uint32_t wf_target_mpaths;   // paths per wavefront batch in units of 2^20 (0: kWfTargetPaths)
     int wf_whole_paths;          // BVH scenes with dynamic fetch, PT_TUNE_WAVEFRONT_WHOLE_PATHS: -1 chosen per render
     int wf_n_queues;             // path queues per buffer set (0, 1 or 2)
+    int pool_max_iterations;     // resident scenes: launches of up to this many iterations go through the path pool
+    int last_launch;             // PT_LAUNCH_* of the last render
     uint32_t wf_sub_capacity;   // paths per sub-queue the buffers were sized for
     uint64_t wf_capacity;       // paths per batch the buffers were sized for
     std::string error;
@@ -201,6 +203,8 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->wf_target_mpaths = 0;
     h->wf_whole_paths = -1;
     h->wf_n_queues = 0;
+    h->pool_max_iterations = 1 << 30;
+    h->last_launch = PT_LAUNCH_NONE;
     h->wf_sub_capacity = 0;
     h->wf_capacity = 0;
 
@@ -602,6 +606,10 @@ int pt_debug_set_tuning(pt_handle h, int key, int value)
         if (value < 0 || value > 4096) break;
         h->wf_target_mpaths = (uint32_t)value;
         return PT_OK;
+    case PT_TUNE_POOL_ITERATIONS:
+        if (value < 0) break;
+        h->pool_max_iterations = value;
+        return PT_OK;
     case PT_TUNE_WAVEFRONT_WHOLE_PATHS:
         if (value < -1 || value > 2) break;
         h->wf_whole_paths = value;
@@ -614,8 +622,9 @@ int pt_debug_set_tuning(pt_handle h, int key, int value)
 
 static uint32_t div_up(uint32_t a, uint32_t b);
 static uint32_t auto_chunks(uint64_t tiles, uint32_t n_iterations);
-static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets);
-static bool takes_wavefront(const pt_context *h, uint64_t last_iteration);
+static uint32_t wavefront_batch_iterations(const pt_context *h, int mode, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets);
+static int wavefront_mode(const pt_context *h, uint32_t n_iterations);
+static bool takes_wavefront(const pt_context *h, uint64_t last_iteration, uint32_t n_iterations);
 static int wavefront_whole_paths(const pt_context *h);
 // Slots per sub-queue for a batch of `iterations` iterations over a w x h rectangle: the batch is
 // dealt out in blocks of 256 paths, block k to sub-queue k % 64, and a sub-queue keeps its survivors.
@@ -624,7 +633,7 @@ static uint64_t wavefront_sub_capacity(uint32_t w, uint32_t h, uint64_t iteratio
     const uint64_t blocks = ((uint64_t)w * h * 4 * iterations + 255) / 256;
     return (blocks + kWfSubQueues - 1) / kWfSubQueues * 256;
 }
-static uint64_t wavefront_bytes_per_path(const pt_context *h);
+static uint64_t wavefront_bytes_per_path(int mode);
 
 int pt_set_memory_limit(pt_handle h, uint64_t bytes)
 {
@@ -651,11 +660,12 @@ int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
     uint64_t steal_next = steal_now, tickets_next = tickets_now, wf_next = wf_now;
     const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
     uint32_t wf_sets = 1;
-    const uint32_t batch_it = n_iterations ? wavefront_batch_iterations(h, paths_per_it, n_iterations, &wf_sets) : 0;
-    if (n_iterations && h->scene_ready && takes_wavefront(h, h->iteration + (uint64_t)n_iterations) && batch_it > 0) {
+    const int wf_mode = wavefront_mode(h, n_iterations);
+    const uint32_t batch_it = n_iterations ? wavefront_batch_iterations(h, wf_mode, paths_per_it, n_iterations, &wf_sets) : 0;
+    if (n_iterations && h->scene_ready && takes_wavefront(h, h->iteration + (uint64_t)n_iterations, n_iterations) && batch_it > 0) {
         const uint64_t capacity = paths_per_it * batch_it;
         const uint64_t sub_cap = wavefront_sub_capacity(h->camera.width, h->camera.height, batch_it);
-        const uint64_t n_queues = (wavefront_bytes_per_path(h) - 3 * sizeof(float)) / queue_bytes;
+        const uint64_t n_queues = (wavefront_bytes_per_path(wf_mode) - 3 * sizeof(float)) / queue_bytes;
         const uint64_t need = wf_sets * (n_queues * sub_cap * kWfSubQueues * queue_bytes + capacity * 3 * sizeof(float) + counts);
         if (need > wf_next) wf_next = need;
     } else if (n_iterations && h->scene_ready && !h->wavefront && h->steal && !h->steal_alloc_failed &&
@@ -744,19 +754,36 @@ static int wavefront_whole_paths(const pt_context *h)
     return h->memory_limit / (kWfQueueRecord + 3 * sizeof(float)) >= paths_per_it ? 2 : 1;
 }
 
-static uint64_t wavefront_bytes_per_path(const pt_context *h)
+// Launches of a few iterations over a scene that is rendered by the linear scan from LDS: the
+// path pool (wf_pool_kernel) instead of the megakernel, whose lanes own pixels.
+static bool takes_pool(const pt_context *h, uint64_t last_iteration, uint32_t n_iterations)
 {
-    const int mode = wavefront_whole_paths(h);
-    return (mode == 1 ? 0 : mode == 2 ? 1 : 2) * kWfQueueRecord + 3 * sizeof(float);
+    SceneParams s;
+    fill_scene(h, s);
+    return h->auto_variant && h->band_world == 1 && h->integrator == PT_INTEGRATOR_PATH && s.bvh.n_nodes == 0 &&
+           !scene_streams(s) && n_iterations > 0 && n_iterations <= (uint32_t)h->pool_max_iterations &&
+           last_iteration < (1u << 30);
+}
+
+// How a render of n_iterations maps to launches: 0..2 as wavefront_whole_paths, 3: the path pool.
+static int wavefront_mode(const pt_context *h, uint32_t n_iterations)
+{
+    if (!h->wavefront && takes_pool(h, h->iteration + (uint64_t)n_iterations, n_iterations)) return 3;
+    return wavefront_whole_paths(h);
+}
+
+static uint64_t wavefront_bytes_per_path(int mode)
+{
+    return (mode == 0 ? 2 : mode == 2 ? 1 : 0) * kWfQueueRecord + 3 * sizeof(float);
 }
 
 // Iterations per wavefront batch of a frame with `paths_per_it` paths per iteration, within the
 // handle's memory limit; 0 when not even one iteration fits.  A render of more iterations than
 // that runs as several batches alternating between two buffer sets of half the size each
 // (*sets = 2); when half the memory does not hold one iteration, one set takes all of it.
-static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets = nullptr)
+static uint32_t wavefront_batch_iterations(const pt_context *h, int mode, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets = nullptr)
 {
-    const uint64_t per_path = wavefront_bytes_per_path(h);
+    const uint64_t per_path = wavefront_bytes_per_path(mode);
     uint64_t target = h->wf_target_mpaths ? (uint64_t)h->wf_target_mpaths << 20 : kWfTargetBytes / per_path;
     if (h->memory_limit && h->memory_limit / per_path < target) target = h->memory_limit / per_path;
     uint32_t n_sets = 2;
@@ -773,9 +800,9 @@ static uint32_t wavefront_batch_iterations(const pt_context *h, uint64_t paths_p
 
 // `sets` sets of queues, per-path radiance and counters for batches of `capacity` paths (kept while
 // they suffice).  A failed allocation frees what was allocated and reports PT_ERR_NOMEM.
-static int ensure_wavefront(pt_context *h, uint64_t capacity, uint64_t sub_cap64, uint32_t sets, size_t *counts_bytes_out)
+static int ensure_wavefront(pt_context *h, int mode, uint64_t capacity, uint64_t sub_cap64, uint32_t sets, size_t *counts_bytes_out)
 {
-    const int n_queues = (int)((wavefront_bytes_per_path(h) - 3 * sizeof(float)) / kWfQueueRecord);
+    const int n_queues = (int)((wavefront_bytes_per_path(mode) - 3 * sizeof(float)) / kWfQueueRecord);
     if (sub_cap64 > 0xffffff00ull) return fail(h, PT_ERR_INVALID, "wavefront variant: image too large");
     const uint32_t sub_cap = (uint32_t)sub_cap64;
     const size_t counts_bytes = (size_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
@@ -807,7 +834,7 @@ static int ensure_wavefront(pt_context *h, uint64_t capacity, uint64_t sub_cap64
             (void)hipGetLastError();
             free_wavefront(h);
             return fail(h, PT_ERR_NOMEM, "wavefront variant: cannot allocate queues for %u x %llu paths (%llu MiB)", sets,
-                        (unsigned long long)capacity, (unsigned long long)(sets * capacity * wavefront_bytes_per_path(h) >> 20));
+                        (unsigned long long)capacity, (unsigned long long)(sets * capacity * wavefront_bytes_per_path(mode) >> 20));
         }
         h->wf_capacity = capacity;
         h->wf_sub_capacity = sub_cap;
@@ -831,7 +858,7 @@ static void fill_wavefront(const pt_context *h, WavefrontParams &p)
 // One batch in buffer set `set` on `stream`: a launch per bounce over the compacted queues, then
 // the resolve -- after the resolve of the batch before (`after`, the other set's event, or null):
 // the frame buffer takes the batches' iterations in order.
-static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, size_t counts_bytes, int set, hipStream_t stream,
+static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, int mode, size_t counts_bytes, int set, hipStream_t stream,
                                   hipEvent_t after)
 {
     const bool tiled = scene_streams(p.scene);
@@ -841,11 +868,11 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, size_t coun
     PT_HIP(h, hipMemsetAsync(pipe.counts, 0, counts_bytes, stream));
     const uint64_t batch_paths = (uint64_t)p.n_iterations * p.rect_w * p.rect_h * 4;
     PT_HIP(h, hipMemsetAsync(pipe.radiance, 0, batch_paths * 3 * sizeof(float), stream));
-    const int mode = wavefront_whole_paths(h);
-    const int last = mode == 1 ? 0 : mode == 2 ? (h->max_bounces < 1 ? h->max_bounces : 1) : h->max_bounces;
+    const int last = mode == 1 || mode == 3 ? 0 : mode == 2 ? (h->max_bounces < 1 ? h->max_bounces : 1) : h->max_bounces;
     for (int b = 0; b <= last; ++b) {
         p.bounce = b;
         p.whole_paths = mode == 1 || (mode == 2 && b == 1);
+        p.path_pool = mode == 3;
         p.out = pipe.queue[b & 1];          // not written by a whole-path launch
         p.in = pipe.queue[(b & 1) ^ 1];
         PT_HIP(h, launch_wavefront_step(p, tiled, stream));
@@ -860,17 +887,18 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, size_t coun
 // Returns PT_ERR_NOMEM (nothing rendered, nothing held) when the queues do not fit.
 static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
 {
+    const int mode = wavefront_mode(h, n_iterations);
     if (h->band_world > 1) return fail(h, PT_ERR_STATE, "the wavefront variant does not support row bands");
     const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
     if (h->iteration + (uint64_t)n_iterations >= (1u << 30))
         return fail(h, PT_ERR_INVALID, "wavefront variant: iteration numbers must stay below 2^30");
     uint32_t sets = 1;
-    const uint32_t batch_it = wavefront_batch_iterations(h, paths_per_it, n_iterations, &sets);
+    const uint32_t batch_it = wavefront_batch_iterations(h, mode, paths_per_it, n_iterations, &sets);
     if (batch_it == 0)
         return fail(h, PT_ERR_NOMEM, "wavefront variant: one iteration needs %llu MiB of queues, the memory limit is %llu MiB",
-                    (unsigned long long)(paths_per_it * wavefront_bytes_per_path(h) >> 20), (unsigned long long)(h->memory_limit >> 20));
+                    (unsigned long long)(paths_per_it * wavefront_bytes_per_path(mode) >> 20), (unsigned long long)(h->memory_limit >> 20));
     size_t counts_bytes = 0;
-    const int rc = ensure_wavefront(h, paths_per_it * batch_it, wavefront_sub_capacity(h->camera.width, h->camera.height, batch_it),
+    const int rc = ensure_wavefront(h, mode, paths_per_it * batch_it, wavefront_sub_capacity(h->camera.width, h->camera.height, batch_it),
                                     sets, &counts_bytes);
     if (rc != PT_OK) return rc;
 
@@ -894,7 +922,7 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
         p.n_iterations = n;
         p.overwrite = h->accum_mode == PT_ACCUM_RUNNING_MEAN ? (p.first_iteration == 1)
                                                              : ((h->fresh && done == 0) ? 1 : 0);
-        const int brc = launch_wavefront_batch(h, p, counts_bytes, set, set ? h->wf_stream2 : h->stream, before);
+        const int brc = launch_wavefront_batch(h, p, mode, counts_bytes, set, set ? h->wf_stream2 : h->stream, before);
         if (brc != PT_OK) return brc;
         before = h->wf_pipe[set].resolved;
         done += n;
@@ -904,6 +932,7 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
     if (before == h->wf_pipe[1].resolved) PT_HIP(h, hipStreamWaitEvent(h->stream, before, 0));
     PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
     h->timed = true;
+    h->last_launch = mode == 3 ? PT_LAUNCH_PATH_POOL : mode == 0 ? PT_LAUNCH_WAVEFRONT : PT_LAUNCH_WAVEFRONT_WHOLE_PATHS;
     h->iteration += n_iterations;
     h->fresh = false;
     return PT_OK;
@@ -928,9 +957,10 @@ static uint32_t auto_chunks(uint64_t tiles, uint32_t n_iterations)
 // PT_VARIANT_AUTO on a BVH scene: BVH traversals differ so much in length that the queue-fed
 // persistent waves are twice as fast as the megakernel (measured); everything else stays with
 // the megakernel.
-static bool takes_wavefront(const pt_context *h, uint64_t last_iteration)
+static bool takes_wavefront(const pt_context *h, uint64_t last_iteration, uint32_t n_iterations)
 {
     if (h->wavefront) return true;
+    if (takes_pool(h, last_iteration, n_iterations)) return true;
     return h->auto_variant && h->accel == PT_ACCEL_AUTO && h->bvh.n_nodes > 0 && h->band_world == 1 &&
            h->integrator == PT_INTEGRATOR_PATH && last_iteration < (1u << 30);
 }
@@ -1041,6 +1071,7 @@ static int enqueue_megakernel(pt_context *h, float *dbuf, uint32_t n_iterations,
             PT_HIP(h, launch_render(p, grid_x, grid_y, tiled, false, h->stream));
         PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
         h->timed = true;
+        h->last_launch = p.steal_scratch ? PT_LAUNCH_MEGAKERNEL_STEALING : PT_LAUNCH_MEGAKERNEL;
     }
     h->iteration += n_iterations;
     h->fresh = false;
@@ -1056,7 +1087,7 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
     if (h->iteration > 0xffffffffu - n_iterations) return fail(h, PT_ERR_INVALID, "iteration counter overflow");
     if (h->wavefront && h->integrator != PT_INTEGRATOR_PATH)
         return fail(h, PT_ERR_STATE, "the wavefront variant only implements PT_INTEGRATOR_PATH");
-    if (takes_wavefront(h, h->iteration + (uint64_t)n_iterations)) {
+    if (takes_wavefront(h, h->iteration + (uint64_t)n_iterations, n_iterations)) {
         const int rc = enqueue_wavefront(h, dbuf, n_iterations);
         // PT_VARIANT_AUTO: when the queues cannot be had the megakernel renders the same image
         if (rc != PT_ERR_NOMEM || h->wavefront) return rc;
@@ -1194,6 +1225,13 @@ int pt_reset_counters(pt_handle h)
     return PT_OK;
 }
 
+int pt_last_launch(pt_handle h, int *kind)
+{
+    if (!h || !kind) return PT_ERR_INVALID;
+    *kind = h->last_launch;
+    return PT_OK;
+}
+
 int pt_last_kernel_ms(pt_handle h, float *ms)
 {
     if (!h || !ms) return PT_ERR_INVALID;
@@ -1237,9 +1275,10 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
     DBG_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
     // The rectangle goes through the kernels a render of this instance would use: the per-bounce
     // wavefront launches, the work-stealing megakernel, or the plain one.
-    if (takes_wavefront(h, iteration) && h->integrator == PT_INTEGRATOR_PATH && iteration < (1u << 30)) {
+    if (takes_wavefront(h, iteration, 1) && h->integrator == PT_INTEGRATOR_PATH && iteration < (1u << 30)) {
+        const int mode = wavefront_mode(h, 1);
         size_t counts_bytes = 0;
-        rc = ensure_wavefront(h, n_paths, wavefront_sub_capacity(x1 - x0, y1 - y0, 1), 1, &counts_bytes);
+        rc = ensure_wavefront(h, mode, n_paths, wavefront_sub_capacity(x1 - x0, y1 - y0, 1), 1, &counts_bytes);
         if (rc != PT_OK) goto cleanup;
         WavefrontParams p;
         fill_wavefront(h, p);
@@ -1251,7 +1290,7 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
         p.buffer = nullptr;
         p.ray_counter = d_cnt;
         p.hit_ids = d_hits; p.pixel_rgb = d_rgb;
-        rc = launch_wavefront_batch(h, p, counts_bytes, 0, h->stream, nullptr);
+        rc = launch_wavefront_batch(h, p, mode, counts_bytes, 0, h->stream, nullptr);
         if (rc != PT_OK) goto cleanup;
         // the batch's per-path radiance buffer has the layout of `radiance`
         if (radiance) DBG_HIP(hipMemcpyAsync(radiance, h->wf_pipe[0].radiance, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));

@@ -332,6 +332,115 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
     if (WHOLE && p.ray_counter && continued && lane == 0) atomicAdd(p.ray_counter, continued);
 }
 
+// Path pool for resident scenes (linear scan, a few iterations per launch): persistent waves, no
+// lane owns a pixel.  A launch of one iteration through the megakernel gives every lane the four
+// paths of its pixel; the lanes of a wave need different numbers of bounces for them, and what the
+// early ones wait is a fifth of the launch (lanes with a ray 0.79), on top of 8160 workgroup
+// start-ups for four paths per lane.  Here a lane whose path ended takes the next camera ray of
+// its wave's pool, whatever pixel it belongs to; the path's radiance goes to the per-path buffer
+// and wf_resolve folds the buffer into the frame in the reference's order.  The pool: the wave
+// generates 64 camera rays at a time with all lanes active (paths of the batch in the order of
+// the static kernel's bounce 0, 64 consecutive items of the workgroup's sub-queue per refill) into
+// a ring of 128 entries in LDS, idle lanes pop.
+constexpr uint32_t kPoolRing = 128;
+struct PoolEntry { float dx, dy, dz; uint32_t pix, it_sub; };
+
+__global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontParams p)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int tid = threadIdx.x;
+    const uint32_t lane = (uint32_t)tid & 63u;
+    const uint32_t q = blockIdx.x;
+    const uint32_t n_pix = p.rect_w * p.rect_h;
+    const uint64_t n_paths = (uint64_t)p.n_iterations * n_pix * 4;
+    const uint64_t blocks = (n_paths + kBlockThreads - 1) / kBlockThreads;
+    const uint32_t n_items = (uint32_t)((blocks + kWfSubQueues - 1 - q) / kWfSubQueues) * kBlockThreads;
+    if (blockIdx.y * (uint32_t)kBlockThreads >= n_items) return;   // uniform for the workgroup
+    uint32_t *cursor = count_ptr(p.counts, 0, q) + 1;
+
+    const SceneView sc = stage_scene<false>(p.scene, lds_raw, tid);
+    PoolEntry *ring = reinterpret_cast<PoolEntry *>(lds_raw + scene_lds_bytes_dev(p.scene)) + (tid >> 6) * kPoolRing;
+    const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
+
+    uint32_t head = 0, count = 0;          // the wave's ring (wave-uniform)
+    bool exhausted = false;                // the sub-queue has no more items
+    unsigned long long continued = 0;      // Intersect calls beyond the camera rays (wave-uniform)
+    bool has = false;
+    V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f), T = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
+    uint32_t pix = 0, it_sub = 0;
+    int b = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle) {
+            if (count < n_idle && !exhausted) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, 64u);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + 64u >= n_items) exhausted = true;
+                const uint32_t j = base + lane;
+                const uint64_t i = ((uint64_t)(j >> 8) * kWfSubQueues + q) * kBlockThreads + (j & 255u);
+                const bool valid = j < n_items && i < n_paths;
+                PoolEntry e = {0.f, 0.f, 1.f, 0u, 0u};
+                if (valid) {
+                    const uint32_t sub = (uint32_t)(i & 3);
+                    const uint64_t ip = i >> 2;
+                    const uint32_t it_off = (uint32_t)(ip / n_pix);
+                    uint32_t x, y;
+                    e.pix = rect_to_frame(p, (uint32_t)(ip - (uint64_t)it_off * n_pix), x, y);
+                    e.it_sub = ((p.first_iteration + it_off) << 2) | sub;
+                    const V3 dir = camera_ray(p.cam, x, y, e.pix, e.it_sub >> 2, (int)sub, k0, k1);
+                    e.dx = dir.x; e.dy = dir.y; e.dz = dir.z;
+                }
+                const unsigned long long vmask = __ballot(valid);
+                const uint32_t vrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(vmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vmask, 0u));
+                if (valid) ring[(head + count + vrank) & (kPoolRing - 1)] = e;
+                count += (uint32_t)__popcll(vmask);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (!has && rank < count) {
+                const PoolEntry e = ring[(head + rank) & (kPoolRing - 1)];
+                o = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+                d = mk(e.dx, e.dy, e.dz);
+                T = mk(1.f, 1.f, 1.f);
+                L = mk(0.f, 0.f, 0.f);
+                pix = e.pix; it_sub = e.it_sub;
+                b = 0;
+                has = true;
+            }
+            const uint32_t taken = n_idle < count ? n_idle : count;
+            head += taken;
+            count -= taken;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!__any(has)) {
+            if (exhausted && count == 0) break;
+            continue;   // a refill brought no valid item yet (the batch's last, partly empty block)
+        }
+
+        float tmax;
+        int best;
+        intersect_scene<false, false>(p.scene, sc, lds_raw, tid, has, o, d, tmax, best);
+        bool cont = false;
+        if (has) {
+            bool end = true;
+            record_hit(p, n_pix, pix, it_sub, b, best);
+            if (best >= 0) {
+                end = shade_bounce(sc, sc.sph[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
+                bank_radiance(p, n_pix, pix, it_sub, L);
+            }
+            cont = !end;
+            has = cont;
+        }
+        continued += (unsigned long long)__popcll(__ballot(cont));
+    }
+    // the resolve kernel counts the camera rays
+    if (p.ray_counter && continued && lane == 0) atomicAdd(p.ray_counter, continued);
+}
+
 // Folds the batch's path radiances into the frame buffer: per pixel, iteration by iteration,
 // c = (((0+L0)+L1)+L2)+L3) * 1/4 and the running mean / sum of RenderKernel (pathtracer.cu:94-109).
 __global__ __launch_bounds__(kBlockThreads) void wf_resolve_kernel(const WavefrontParams p)
@@ -406,6 +515,18 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
     const uint32_t chunks = p.sub_capacity / kBlockThreads;
     const dim3 grid(kWfSubQueues, chunks < 32u ? chunks : 32u), block(kBlockThreads);
     const bool bvh = p.scene.bvh.n_nodes > 0;   // BVH kernels read the scene from global memory
+    if (p.path_pool && !bvh && !tiled) {
+        // one resident set of persistent workgroups: 8 per CU (8 waves per SIMD), fewer if LDS says so
+        const size_t pool_lds = scene_lds_bytes(p.scene, false) + (kBlockThreads / 64) * kPoolRing * sizeof(PoolEntry);
+        uint32_t per_cu = (uint32_t)((160u * 1024u) / pool_lds);
+        if (per_cu > 8u) per_cu = 8u;
+        if (per_cu < 1u) per_cu = 1u;
+        const uint32_t rows = (per_cu * (uint32_t)current_device_cus() + kWfSubQueues - 1) / kWfSubQueues;
+        const uint32_t pool_chunks = p.sub_capacity / kBlockThreads;
+        hipLaunchKernelGGL(wf_pool_kernel, dim3(kWfSubQueues, pool_chunks < rows ? pool_chunks : rows), dim3(kBlockThreads),
+                           pool_lds, stream, p);
+        return hipGetLastError();
+    }
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : scene_lds_bytes(p.scene, tiled);
     if (bvh && p.dynamic_fetch) {
         // One resident set of persistent workgroups: per CU as many as the traversal stacks in LDS

@@ -156,9 +156,13 @@ int pt_set_row_bands(pt_handle h, uint32_t band_rows, uint32_t rank, uint32_t wo
 int pt_ray_count(pt_handle h, uint64_t *out);
 int pt_reset_counters(pt_handle h);
 /* Kernel variant; results are bit-identical in all of them.
- *   PT_VARIANT_AUTO (default): PT_VARIANT_WAVEFRONT for scenes rendered through the sphere BVH
- *     (when no row bands are set, the integrator is PT_INTEGRATOR_PATH and the queues fit the
- *     memory limit), else PT_VARIANT_STEALING
+ *   PT_VARIANT_AUTO (default), when no row bands are set, the integrator is PT_INTEGRATOR_PATH
+ *     and the buffers fit the memory limit: PT_VARIANT_WAVEFRONT for scenes rendered through the
+ *     sphere BVH; the path pool for scenes that fit LDS (up to 512 spheres): persistent waves
+ *     whose lanes take the next camera ray of the batch, whatever pixel it belongs to, when their
+ *     path has ended, 12 bytes of radiance per path in flight folded into the frame in the
+ *     reference's order afterwards, batches on two streams like PT_VARIANT_WAVEFRONT's.
+ *     Everything else: PT_VARIANT_STEALING
  *   PT_VARIANT_STEALING: PT_VARIANT_REGENERATION, and a lane that has finished its pixel takes
  *     work over from the lane of its wave with the most left: whole pixel-iterations, or single
  *     paths in launches of up to 5 iterations (pt_run's one iteration per call).  Applies to every
@@ -198,6 +202,9 @@ int pt_set_kernel_variant(pt_handle h, int variant);
  *                              scan; reset by pt_init_scene)
  *   PT_TUNE_WAVEFRONT_BATCH    paths in flight of the wavefront variant in units of 2^20 (0: the
  *                              default; kept across variant changes)
+ *   PT_TUNE_POOL_ITERATIONS    PT_VARIANT_AUTO, scenes that fit LDS: launches of up to this many
+ *                              iterations go through the path pool (default 2^30; 0: never, the
+ *                              work-stealing megakernel renders; kept across variant changes)
  *   PT_TUNE_WAVEFRONT_WHOLE_PATHS  BVH scenes, how bounces map to launches: 0: one launch per
  *                              bounce over two queues (100 bytes per path in flight); 2: the
  *                              camera rays in a launch of their own, then one launch that follows
@@ -208,7 +215,7 @@ int pt_set_kernel_variant(pt_handle h, int variant);
  *                              memory limit (kept across variant changes) */
 enum { PT_TUNE_REGEN_MIN_IDLE = 0, PT_TUNE_CAMERA_RAY_RING = 1, PT_TUNE_STEAL_UNIT = 2, PT_TUNE_ITERATION_RANGES = 3,
        PT_TUNE_WAVEFRONT_REFILL = 4, PT_TUNE_BVH_NODE_STEPS = 5, PT_TUNE_BVH_STACK = 6, PT_TUNE_WAVEFRONT_BATCH = 7,
-       PT_TUNE_WAVEFRONT_WHOLE_PATHS = 8 };
+       PT_TUNE_WAVEFRONT_WHOLE_PATHS = 8, PT_TUNE_POOL_ITERATIONS = 9 };
 int pt_debug_set_tuning(pt_handle h, int key, int value);
 /* Device memory held by the instance: bytes[0] = allocated now (scene, BVH, scratch pool,
  * tickets, wavefront queues, internal frame buffer); bytes[1] = what a pt_run_n of n_iterations
@@ -275,6 +282,11 @@ int pt_accel_stats(pt_handle h, uint64_t out[32]);
 int pt_lane_stats(pt_handle h, uint64_t out[64]);
 /* HIP-event time of the last pt_run/pt_run_n launch in milliseconds (waits for it). */
 int pt_last_kernel_ms(pt_handle h, float *ms);
+/* Which kernels the last pt_run / pt_run_n / pt_run_n_noalloc went through (what PT_VARIANT_AUTO
+ * resolved to for that scene and launch).  Has no counterpart in the reference (measurement only). */
+enum { PT_LAUNCH_NONE = 0, PT_LAUNCH_MEGAKERNEL = 1, PT_LAUNCH_MEGAKERNEL_STEALING = 2, PT_LAUNCH_WAVEFRONT = 3,
+       PT_LAUNCH_WAVEFRONT_WHOLE_PATHS = 4, PT_LAUNCH_PATH_POOL = 5 };
+int pt_last_launch(pt_handle h, int *kind);
 
 /* Copies a device frame buffer to the host (pt_read_image(h, dev, host)); with PT_ACCUM_SUM
  * the caller divides by the number of iterations. */

@@ -681,18 +681,46 @@ def test_variants_tuning_and_memory_footprint(pt, torch_cuda):
     cam = pt.Camera(eye, look, up, 640, 360, 0, 0, fov)
     tr = pt.Pathtracer(cam, 8, 1)
     tr.Init(mats, sph, lights)
+    # PT_VARIANT_AUTO on a scene that fits LDS: the path pool, 12 bytes of radiance per path
+    ppi = 640 * 360 * 4
+    now, nxt = tr.MemoryFootprint(8)
+    assert now < 4096 and 12 * ppi * 8 <= nxt - now <= 12 * ppi * 8 + 2**20
+    buf = torch_cuda.zeros(640 * 360 * 3, device="cuda")
+    tr.RunN(buf, 8)
+    assert tr.LastLaunch() == pt.LAUNCH_PATH_POOL
+    assert tr.MemoryFootprint(8) == (nxt, nxt)
+    ref8 = buf.cpu().numpy().tobytes()
+    tr.Release()
+    tr = pt.Pathtracer(cam, 8, 1)
+    tr.Init(mats, sph, lights)
+    tr.SetMemoryLimit(12 * ppi * 2 + 2**20)                        # two sets of one iteration each
+    now2, nxt2 = tr.MemoryFootprint(8)
+    assert 12 * ppi * 2 <= nxt2 - now2 <= 12 * ppi * 2 + 2**20
+    tr.RunN(buf, 8)
+    assert tr.LastLaunch() == pt.LAUNCH_PATH_POOL and buf.cpu().numpy().tobytes() == ref8
+    tr.Reset()
+    tr.SetMemoryLimit(12 * ppi - 1)                                # not one iteration's radiance: the megakernel,
+    assert tr.MemoryFootprint(8)[1] == nxt2                        # without its 48 MiB scratch pool either
+    tr.RunN(buf, 8)
+    assert tr.LastLaunch() == pt.LAUNCH_MEGAKERNEL and buf.cpu().numpy().tobytes() == ref8
+    tr.Release()
+    # the work-stealing megakernel on request
+    tr = pt.Pathtracer(cam, 8, 1)
+    tr.Init(mats, sph, lights)
+    tr.SetKernelVariant(pt.VARIANT_STEALING)
     now, nxt = tr.MemoryFootprint(64)
     pool = 48 * 2**20 + 1024
     tiles = 40 * 23
     assert now < 4096 and nxt == now + pool + 4 * (1 + tiles)
     assert tr.MemoryFootprint(4) == (now, now + pool)              # a short launch is not cut into ranges
-    buf = torch_cuda.zeros(640 * 360 * 3, device="cuda")
     tr.RunN(buf, 64)
+    assert tr.LastLaunch() == pt.LAUNCH_MEGAKERNEL_STEALING
     assert tr.MemoryFootprint(64) == (nxt, nxt)
     # the footprint does not grow with the frame: a 4K instance predicts the same pool
     cam4k = pt.Camera(eye, look, up, 3840, 2160, 0, 0, fov)
     big = pt.Pathtracer(cam4k, 8, 1)
     big.Init(mats, sph, lights)
+    big.SetKernelVariant(pt.VARIANT_STEALING)
     b_now, b_next = big.MemoryFootprint(16)
     assert b_next - b_now == pool
     big.SetMemoryLimit(2**20)                                      # no room for the pool: no stealing, nothing allocated
