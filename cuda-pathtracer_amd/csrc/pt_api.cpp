@@ -866,8 +866,10 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, int mode, s
     p.counts = pipe.counts;
     p.path_radiance = pipe.radiance;
     PT_HIP(h, hipMemsetAsync(pipe.counts, 0, counts_bytes, stream));
-    const uint64_t batch_paths = (uint64_t)p.n_iterations * p.rect_w * p.rect_h * 4;
-    PT_HIP(h, hipMemsetAsync(pipe.radiance, 0, batch_paths * 3 * sizeof(float), stream));
+    if (mode != 3) {   // the queue-fed kernels add to the path's entry bounce by bounce; the path pool stores it once
+        const uint64_t batch_paths = (uint64_t)p.n_iterations * p.rect_w * p.rect_h * 4;
+        PT_HIP(h, hipMemsetAsync(pipe.radiance, 0, batch_paths * 3 * sizeof(float), stream));
+    }
     const int last = mode == 1 || mode == 3 ? 0 : mode == 2 ? (h->max_bounces < 1 ? h->max_bounces : 1) : h->max_bounces;
     for (int b = 0; b <= last; ++b) {
         p.bounce = b;

@@ -177,7 +177,7 @@ struct WavefrontParams {
     uint32_t *counts;           // [max_bounces + 2][kWfSubQueues][kWfCountStride]: word 0 = paths alive
                                 // in sub-queue q entering bounce k, word 1 = fetch cursor of the
                                 // dynamic-fetch kernel over those paths
-    float *path_radiance;       // [paths][3], zero when the batch starts
+    float *path_radiance;       // [paths][3], zero when the batch starts (the path pool stores every entry)
     // resolve
     int accum_mode, overwrite;
     float *buffer;              // may be NULL (parity hook)

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
 // early ones wait is a fifth of the launch (lanes with a ray 0.79), on top of 8160 workgroup
 // start-ups for four paths per lane.  Here a lane whose path ended takes the next camera ray of
 // its wave's pool, whatever pixel it belongs to; the path's radiance goes to the per-path buffer
-// and wf_resolve folds the buffer into the frame in the reference's order.  The pool: the wave
+// when the path ends and wf_resolve folds the buffer into the frame in the reference's order.  The pool: the wave
 // generates 64 camera rays at a time with all lanes active (paths of the batch in the order of
 // the static kernel's bounce 0, 64 consecutive items of the workgroup's sub-queue per refill) into
 // a ring of 128 entries in LDS, idle lanes pop.
@@ -428,9 +428,10 @@ __global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontP
         if (has) {
             bool end = true;
             record_hit(p, n_pix, pix, it_sub, b, best);
-            if (best >= 0) {
-                end = shade_bounce(sc, sc.sph[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
-                bank_radiance(p, n_pix, pix, it_sub, L);
+            if (best >= 0) end = shade_bounce(sc, sc.sph[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
+            if (end) {   // the path lived in this lane from its camera ray on: one store, no zeroed buffer needed
+                float *pr = p.path_radiance + batch_path_index(p, n_pix, pix, it_sub) * 3;
+                pr[0] = L.x; pr[1] = L.y; pr[2] = L.z;
             }
             cont = !end;
             has = cont;

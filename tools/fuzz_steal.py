@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised comparison of the work-stealing megakernel (with and without iteration ranges, both
-integrators) with the plain regeneration megakernel: random frame sizes, iteration counts, depths,
+integrators) and of PT_VARIANT_AUTO (the path pool where it applies, with random limits on the paths
+in flight) with the plain regeneration megakernel: random frame sizes, iteration counts, depths,
 scenes (built-in ones and random sphere clouds scanned brute force or through the BVH), continued
 renders, sum buffers and row bands.  Frame buffers and Intersect-call counts must agree bit for bit.
 
@@ -57,13 +58,16 @@ def one_case(seed):
     cam = pt.Camera(eye, look, up, w, h, 0, 0, fov)
     out = {}
     # + 2 / + 3: single paths / whole pixel-iterations change hands; + 10 + k: k + 1 iteration ranges
+    pool_limit = int(rng.choice([0, 0, 12 * w * h * 4 * int(rng.integers(1, 4)) + 2**20]))
     for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING, pt.VARIANT_STEALING + 2, pt.VARIANT_STEALING + 3,
-                    pt.VARIANT_STEALING + 10 + int(rng.integers(1, 6))):
+                    pt.VARIANT_STEALING + 10 + int(rng.integers(1, 6)), pt.VARIANT_AUTO):
         tr = pt.Pathtracer(cam, depth, seed)
         tr.Init(mats, sph, lights)
         tr.SetAccel(accel)
         tr.SetIntegrator(integrator)
         tr.SetKernelVariant(variant)
+        if variant == pt.VARIANT_AUTO:
+            tr.SetMemoryLimit(pool_limit)
         tr.SetAccumMode(mode)
         if bands:
             tr.SetRowBands(*bands)

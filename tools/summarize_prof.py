@@ -45,13 +45,13 @@ def main():
                     continue
                 sums[r["Counter_Name"]] += float(r["Counter_Value"])
                 counts[r["Counter_Name"]] += 1
-                if "wf_step" in r["Kernel_Name"] or "render_" in r["Kernel_Name"]:
-                    kernels.add(r["Kernel_Name"])
+                kernels.add(r["Kernel_Name"])
                 meta = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size",
                                           "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r}
-    # the megakernel is one launch per bench step; the wavefront variant is many launches per
-    # step, so its counters are summed over all launches of the run and divided by the number of
-    # bench steps (warm-up included) to stay comparable
+    # the megakernel is one launch per bench step; the wavefront variant and the path pool are
+    # several launches per step (bounces or batches, and the resolve), so their counters are summed
+    # over all launches of the run and divided by the number of bench steps (warm-up included) to
+    # stay comparable
     n_steps = 1
     for line in cmd.splitlines():
         if line.startswith("{"):
