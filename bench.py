@@ -381,7 +381,7 @@ def main():
         pt.LAUNCH_MEGAKERNEL_STEALING: ("v500", "render_steal_kernel"),
         pt.LAUNCH_WAVEFRONT: ("v100", "wf_step_* (all launches of a step)"),
         pt.LAUNCH_WAVEFRONT_WHOLE_PATHS: ("v100whole", "wf_step_bvh_kernel<whole paths> (all launches of a step)"),
-        pt.LAUNCH_PATH_POOL: ("pool", "wf_pool_kernel"),
+        pt.LAUNCH_PATH_POOL: ("pool", "wf_pool_kernel (+ wf_resolve_kernel; all launches of a step)"),
     }.get(launch, ("none", "none"))
     tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}{'_bvh' if bvh else ''}_{launch_tag}.json")
     pmc = pmc_summary(tpath) if args.integrator == "path" else {}
