@@ -626,6 +626,16 @@ static uint32_t wavefront_batch_iterations(const pt_context *h, int mode, uint64
 static int wavefront_mode(const pt_context *h, uint32_t n_iterations);
 static bool takes_wavefront(const pt_context *h, uint64_t last_iteration, uint32_t n_iterations);
 static int wavefront_whole_paths(const pt_context *h);
+// Rows of the frame this instance renders: all of them, or those of its row bands.
+static uint32_t owned_rows(const pt_context *h)
+{
+    if (h->band_world <= 1) return h->camera.height;
+    uint32_t rows = 0;
+    for (uint32_t y = h->band_rank * h->band_rows; y < h->camera.height; y += h->band_rows * h->band_world)
+        rows += h->camera.height - y < h->band_rows ? h->camera.height - y : h->band_rows;
+    return rows;
+}
+
 // Slots per sub-queue for a batch of `iterations` iterations over a w x h rectangle: the batch is
 // dealt out in blocks of 256 paths, block k to sub-queue k % 64, and a sub-queue keeps its survivors.
 static uint64_t wavefront_sub_capacity(uint32_t w, uint32_t h, uint64_t iterations)
@@ -658,13 +668,13 @@ int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
     bytes[0] = fixed + steal_now + tickets_now + wf_now;
     // what the next render adds: wavefront queues of one batch, or the scratch pool and tickets
     uint64_t steal_next = steal_now, tickets_next = tickets_now, wf_next = wf_now;
-    const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
+    const uint64_t paths_per_it = (uint64_t)h->camera.width * owned_rows(h) * 4;
     uint32_t wf_sets = 1;
     const int wf_mode = wavefront_mode(h, n_iterations);
     const uint32_t batch_it = n_iterations ? wavefront_batch_iterations(h, wf_mode, paths_per_it, n_iterations, &wf_sets) : 0;
-    if (n_iterations && h->scene_ready && takes_wavefront(h, h->iteration + (uint64_t)n_iterations, n_iterations) && batch_it > 0) {
+    if (n_iterations && h->scene_ready && paths_per_it && takes_wavefront(h, h->iteration + (uint64_t)n_iterations, n_iterations) && batch_it > 0) {
         const uint64_t capacity = paths_per_it * batch_it;
-        const uint64_t sub_cap = wavefront_sub_capacity(h->camera.width, h->camera.height, batch_it);
+        const uint64_t sub_cap = wavefront_sub_capacity(h->camera.width, owned_rows(h), batch_it);
         const uint64_t n_queues = (wavefront_bytes_per_path(wf_mode) - 3 * sizeof(float)) / queue_bytes;
         const uint64_t need = wf_sets * (n_queues * sub_cap * kWfSubQueues * queue_bytes + capacity * 3 * sizeof(float) + counts);
         if (need > wf_next) wf_next = need;
@@ -760,7 +770,7 @@ static bool takes_pool(const pt_context *h, uint64_t last_iteration, uint32_t n_
 {
     SceneParams s;
     fill_scene(h, s);
-    return h->auto_variant && h->band_world == 1 && h->integrator == PT_INTEGRATOR_PATH && s.bvh.n_nodes == 0 &&
+    return h->auto_variant && h->integrator == PT_INTEGRATOR_PATH && s.bvh.n_nodes == 0 &&
            !scene_streams(s) && n_iterations > 0 && n_iterations <= (uint32_t)h->pool_max_iterations &&
            last_iteration < (1u << 30);
 }
@@ -890,8 +900,13 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, int mode, s
 static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
 {
     const int mode = wavefront_mode(h, n_iterations);
-    if (h->band_world > 1) return fail(h, PT_ERR_STATE, "the wavefront variant does not support row bands");
-    const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
+    const uint32_t rows = owned_rows(h);
+    const uint64_t paths_per_it = (uint64_t)h->camera.width * rows * 4;
+    if (rows == 0) {   // this rank owns no band of the frame
+        h->iteration += n_iterations;
+        h->fresh = false;
+        return PT_OK;
+    }
     if (h->iteration + (uint64_t)n_iterations >= (1u << 30))
         return fail(h, PT_ERR_INVALID, "wavefront variant: iteration numbers must stay below 2^30");
     uint32_t sets = 1;
@@ -900,7 +915,7 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
         return fail(h, PT_ERR_NOMEM, "wavefront variant: one iteration needs %llu MiB of queues, the memory limit is %llu MiB",
                     (unsigned long long)(paths_per_it * wavefront_bytes_per_path(mode) >> 20), (unsigned long long)(h->memory_limit >> 20));
     size_t counts_bytes = 0;
-    const int rc = ensure_wavefront(h, mode, paths_per_it * batch_it, wavefront_sub_capacity(h->camera.width, h->camera.height, batch_it),
+    const int rc = ensure_wavefront(h, mode, paths_per_it * batch_it, wavefront_sub_capacity(h->camera.width, rows, batch_it),
                                     sets, &counts_bytes);
     if (rc != PT_OK) return rc;
 
@@ -909,6 +924,8 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
     p.accum_mode = h->accum_mode;
     p.buffer = dbuf;
     p.ray_counter = h->d_ray_counter;
+    p.rect_h = rows;
+    if (h->band_world > 1) { p.band_rows = h->band_rows; p.band_rank = h->band_rank; p.band_world = h->band_world; }
 
     PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
     if (sets > 1) {   // the second stream starts after what the caller's stream holds so far
@@ -963,7 +980,7 @@ static bool takes_wavefront(const pt_context *h, uint64_t last_iteration, uint32
 {
     if (h->wavefront) return true;
     if (takes_pool(h, last_iteration, n_iterations)) return true;
-    return h->auto_variant && h->accel == PT_ACCEL_AUTO && h->bvh.n_nodes > 0 && h->band_world == 1 &&
+    return h->auto_variant && h->accel == PT_ACCEL_AUTO && h->bvh.n_nodes > 0 &&
            h->integrator == PT_INTEGRATOR_PATH && last_iteration < (1u << 30);
 }
 

@@ -165,6 +165,7 @@ struct WavefrontParams {
     uint64_t seed;
     int max_bounces;
     uint32_t x0, y0, rect_w, rect_h;   // pixel rectangle of the batch (a render: the whole frame)
+    uint32_t band_rows, band_rank, band_world;   // band_world > 1: the rectangle's rows are the owned row bands
     uint32_t first_iteration;   // of the batch
     uint32_t n_iterations;      // in the batch
     int bounce;                 // bounce index handled by this launch

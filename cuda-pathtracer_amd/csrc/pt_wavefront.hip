@@ -29,18 +29,28 @@ PT_DEV uint32_t *count_ptr(uint32_t *counts, int bounce, uint32_t q)
 // The batch covers the pixel rectangle [x0, x0 + rect_w) x [y0, y0 + rect_h) (the whole frame for a
 // render, a part of it for the parity hook).  Paths are numbered over the rectangle's pixels in
 // row-major order; a path carries its frame-wide pixel index (the Philox counter).
+// With row bands (band_world > 1; full-width rectangle, y0 == 0) the rectangle's rows are the rows
+// this instance owns, band after band: bands b with b % band_world == band_rank.
 PT_DEV uint32_t rect_to_frame(const WavefrontParams &p, uint32_t local, uint32_t &x, uint32_t &y)
 {
     const uint32_t ry = local / p.rect_w;
     x = p.x0 + (local - ry * p.rect_w);
     y = p.y0 + ry;
+    if (p.band_world > 1u) {
+        const uint32_t band = ry / p.band_rows;
+        y = (band * p.band_world + p.band_rank) * p.band_rows + (ry - band * p.band_rows);
+    }
     return y * p.cam.width + x;
 }
 
 PT_DEV uint32_t frame_to_rect(const WavefrontParams &p, uint32_t pix)
 {
-    if (p.rect_w == p.cam.width && p.x0 == 0u && p.y0 == 0u) return pix;   // wave-uniform
+    if (p.rect_w == p.cam.width && p.x0 == 0u && p.y0 == 0u && p.band_world <= 1u) return pix;   // wave-uniform
     const uint32_t y = pix / p.cam.width, x = pix - y * p.cam.width;
+    if (p.band_world > 1u) {
+        const uint32_t period = p.band_rows * p.band_world, k = y / period;
+        return (k * p.band_rows + (y - k * period - p.band_rank * p.band_rows)) * p.rect_w + x;
+    }
     return (y - p.y0) * p.rect_w + (x - p.x0);
 }
 

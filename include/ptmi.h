@@ -156,8 +156,8 @@ int pt_set_row_bands(pt_handle h, uint32_t band_rows, uint32_t rank, uint32_t wo
 int pt_ray_count(pt_handle h, uint64_t *out);
 int pt_reset_counters(pt_handle h);
 /* Kernel variant; results are bit-identical in all of them.
- *   PT_VARIANT_AUTO (default), when no row bands are set, the integrator is PT_INTEGRATOR_PATH
- *     and the buffers fit the memory limit: PT_VARIANT_WAVEFRONT for scenes rendered through the
+ *   PT_VARIANT_AUTO (default), when the integrator is PT_INTEGRATOR_PATH and the buffers fit the
+ *     memory limit (row bands included: the batch then holds the owned rows only): PT_VARIANT_WAVEFRONT for scenes rendered through the
  *     sphere BVH; the path pool for scenes that fit LDS (up to 512 spheres): persistent waves
  *     whose lanes take the next camera ray of the batch, whatever pixel it belongs to, when their
  *     path has ended, 12 bytes of radiance per path in flight folded into the frame in the
@@ -175,7 +175,7 @@ int pt_reset_counters(pt_handle h);
  *   PT_VARIANT_CLASSIC: megakernel, a wave starts new paths only when all its lanes are idle
  *   PT_VARIANT_WAVEFRONT: one launch per bounce over compacted path queues in device memory
  *     (100 bytes per path in flight, up to about 6.7 GB, allocated on first use -- see
- *     pt_memory_footprint and pt_set_memory_limit; no row bands).  A render of more iterations
+ *     pt_memory_footprint and pt_set_memory_limit).  A render of more iterations
  *     than fit runs as batches that alternate between two buffer sets on two streams (the
  *     caller's and one of the instance's), so that one batch's launches fill the chip while the
  *     other's last traversals finish; the caller's stream ends behind both.  BVH scenes:

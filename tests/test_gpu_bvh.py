@@ -324,3 +324,35 @@ def test_two_buffer_sets_respect_the_callers_stream(pt, torch_cuda):
     assert out.cpu().numpy().tobytes() == ref
     assert buf.cpu().numpy().tobytes() == ref
     tr.Release()
+
+
+def test_row_bands_through_the_wavefront_launches(pt, torch_cuda):
+    """Tile split on a BVH scene: every rank's batch holds the rows of its 16-row bands only (the
+    last band of the frame is a partial one), the queue-fed launches render them, and the ranks'
+    frames add up to the single-instance image bit for bit; so do the ray counts."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    mats = materials(pt, [(0, 0.0), (1, 0.9), (2, 1.33), (0, 0.0)])
+    walls, lights = room(pt, (0, 40, -20), 60)
+    sph = np.concatenate([walls, cloud(pt, rng, 900, (0, 40, -20), 50, 0.5, 2.5, 4)])
+    cam = pt.Camera([0, 45, 35], [0, 38, -20], [0, 1, 0], 150, 107, 0, 0, 60.0)   # 6 full bands + 11 rows
+    tr = pt.Pathtracer(cam, 8, 2)
+    tr.Init(mats, sph, lights)
+    tr.ResetCounters()
+    ref = render(torch, tr, 1, 3)
+    ref_rays = tr.RayCount()
+    assert tr.LastLaunch() == pt.LAUNCH_WAVEFRONT
+    for world in (3, 8):
+        total = torch.zeros_like(ref)
+        rays = 0
+        for rank in range(world):
+            tr.SetRowBands(16, rank, world)
+            tr.ResetCounters()
+            part = render(torch, tr, 1, 3)
+            if rank * 16 < 107:      # with 8 ranks the last one owns no band of this frame
+                assert tr.LastLaunch() == pt.LAUNCH_WAVEFRONT
+            rays += tr.RayCount()
+            total += part
+        assert total.cpu().numpy().tobytes() == ref.cpu().numpy().tobytes(), world
+        assert rays == ref_rays
+    tr.Release()

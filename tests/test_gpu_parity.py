@@ -49,9 +49,9 @@ def render(torch, tr, first_iteration, n_iterations, batched=True, buf=None):
     return buf
 
 
-# The kernels a render goes through: what ships by default (PT_VARIANT_AUTO: the work-stealing
-# megakernel, or the per-bounce wavefront launches for BVH scenes) and the plain megakernel.
-SHIPPED_VARIANTS = [-1, 0]   # pt.VARIANT_AUTO, pt.VARIANT_REGENERATION
+# The kernels a render goes through: what ships by default (PT_VARIANT_AUTO: the path pool, or the
+# per-bounce wavefront launches for BVH scenes), the plain megakernel and the work-stealing one.
+SHIPPED_VARIANTS = [-1, 0, 500]   # pt.VARIANT_AUTO (path pool / BVH wavefront), pt.VARIANT_REGENERATION, pt.VARIANT_STEALING
 
 
 @pytest.mark.parametrize("variant", SHIPPED_VARIANTS)
@@ -240,13 +240,22 @@ def test_wavefront_variant_matches_golden_bit_exact(pt, torch_cuda, name):
     tr.Release()
 
 
-def test_wavefront_rejects_row_bands(pt, torch_cuda):
+def test_wavefront_renders_row_bands(pt, torch_cuda):
+    """The per-bounce launches over a linear-scan scene with row bands: the two ranks' frames add up
+    to the fixture's image (one iteration, so sum == mean)."""
     g = load_golden("demo_32x32_d0_it1")
     tr = make_tracer(pt, g, pt.VARIANT_WAVEFRONT)
-    tr.SetRowBands(16, 0, 2)
-    with pytest.raises(pt.PtError) as e:
-        tr.Run(torch_cuda.zeros(32 * 32 * 3, device="cuda"))
-    assert e.value.code == pt.PT_ERR_STATE
+    total = torch_cuda.zeros(32 * 32 * 3, device="cuda")
+    for rank in range(2):
+        tr.SetRowBands(16, rank, 2)
+        tr.Reset()
+        buf = torch_cuda.zeros(32 * 32 * 3, device="cuda")
+        tr.Run(buf)
+        assert tr.LastLaunch() == pt.LAUNCH_WAVEFRONT
+        half = buf.cpu().numpy().reshape(32, 32, 3)
+        assert not half[16 * (1 - rank):16 * (2 - rank)].any()      # the other rank's band stays untouched
+        total += buf
+    assert total.cpu().numpy().tobytes() == g["image"].tobytes()
     tr.Release()
 
 
@@ -544,21 +553,26 @@ def _oracle_bands(O, cam, mats, sph, lights, depth, n, bands):
 
 def test_config2_as_benchmarked_1080p_64_iterations(pt, O, torch_cuda):
     """The headline configuration exactly as bench.py times it: demo scene, 1920x1080, depth 8,
-    64 iterations in ONE pt_run_n with the default variant -- 8160 tiles x 3 iteration ranges, about
-    24 000 workgroups for some 1 500 resident slots, so the ticket order, the per-tile hand-over of
-    the frame buffer between workgroups (possibly on different XCDs) and the scratch-block pool all
-    work under real oversubscription.  Against the plain megakernel (image bytes, ray count), a
-    forced 4-range launch, and oracle row bands at the top, middle and bottom of the frame."""
+    64 iterations in ONE pt_run_n with the default variant -- the path pool, two batches of 32
+    iterations on two buffer sets and two streams.  The same through the work-stealing megakernel:
+    8160 tiles x 3 iteration ranges, about 24 000 workgroups for some 1 500 resident slots, so the
+    ticket order, the per-tile hand-over of the frame buffer between workgroups (possibly on
+    different XCDs) and the scratch-block pool all work under real oversubscription.  Against the
+    plain megakernel (image bytes, ray count), a forced 4-range launch, and oracle row bands at the
+    top, middle and bottom of the frame."""
     mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
     cam = pt.Camera(eye, look, up, 1920, 1080, 0, 0, fov)
     imgs, rays = {}, {}
-    for variant in (pt.VARIANT_AUTO, pt.VARIANT_REGENERATION, pt.VARIANT_STEALING + 13):
+    expect = {pt.VARIANT_AUTO: pt.LAUNCH_PATH_POOL, pt.VARIANT_REGENERATION: pt.LAUNCH_MEGAKERNEL,
+              pt.VARIANT_STEALING: pt.LAUNCH_MEGAKERNEL_STEALING, pt.VARIANT_STEALING + 13: pt.LAUNCH_MEGAKERNEL_STEALING}
+    for variant in expect:
         tr = pt.Pathtracer(cam, 8, 1)
         tr.Init(mats, sph, lights)
         tr.SetKernelVariant(variant)
         tr.ResetCounters()
         imgs[variant] = render(torch_cuda, tr, 1, 64).cpu().numpy().reshape(1080, 1920, 3)
         rays[variant] = tr.RayCount()
+        assert tr.LastLaunch() == expect[variant], variant
         tr.Release()
     ref = imgs[pt.VARIANT_REGENERATION]
     for variant in imgs:
