@@ -749,19 +749,20 @@ static const uint64_t kWfTargetBytes = (64ull << 20) * kWfBytesPerPath;
 //   1  one launch per batch follows every path from its camera ray to its end (no queues, 12 bytes)
 //   2  the camera rays in a launch of their own, a second launch follows every surviving path from
 //      its first bounce to its end (one queue, 56 bytes)
-// Measured on the 10 007-sphere scene, 1080p x 16 iterations: mode 0 92.5 ms, mode 2 96.2, mode 1
-// 98.4.  Camera rays are coherent and trace at twice the rate of scattered rays as long as they
-// share waves with each other, and a queue keeps even the scattered rays in runs that started in
-// the same 64 pixels; a lane that keeps its path gives that up.  So: one launch per bounce unless
-// asked otherwise, and the leaner modes when the memory limit has no room for one iteration of the
-// fuller one.
+// Measured on the 10 007-sphere scene, 1080p x 16 iterations (ms, HBM bytes per render):
+// mode 0 91.5 ms, 38.8 GB; mode 2 92.2 ms, 12.7 GB; mode 1 96.3 ms, 2.3 GB.
+// Camera rays are coherent and trace at twice the rate of scattered rays as long as they share
+// waves with each other, which mode 1 gives up; a queue also keeps the scattered rays in the runs
+// a wave appended together, which is worth the last 0.7 % of mode 0.  The default is mode 2: a
+// third of the traffic and 56 instead of 100 bytes per path in flight for that 0.7 %; mode 1 when
+// the memory limit has no room for one iteration's queue.
 static int wavefront_whole_paths(const pt_context *h)
 {
     if (h->wf_dynamic_fetch <= 0 || h->accel != PT_ACCEL_AUTO || h->bvh.n_nodes == 0) return 0;
     if (h->wf_whole_paths >= 0) return h->wf_whole_paths;
     const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
-    if (!h->memory_limit || h->memory_limit / kWfBytesPerPath >= paths_per_it) return 0;
-    return h->memory_limit / (kWfQueueRecord + 3 * sizeof(float)) >= paths_per_it ? 2 : 1;
+    if (h->memory_limit && h->memory_limit / (kWfQueueRecord + 3 * sizeof(float)) < paths_per_it) return 1;
+    return 2;
 }
 
 // Launches of a few iterations over a scene that is rendered by the linear scan from LDS: the

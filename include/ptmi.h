@@ -174,7 +174,8 @@ int pt_reset_counters(pt_handle h);
  *   PT_VARIANT_REGENERATION: megakernel, persistent lanes with path regeneration
  *   PT_VARIANT_CLASSIC: megakernel, a wave starts new paths only when all its lanes are idle
  *   PT_VARIANT_WAVEFRONT: one launch per bounce over compacted path queues in device memory
- *     (100 bytes per path in flight, up to about 6.7 GB, allocated on first use -- see
+ *     (100 bytes per path in flight, or 56 / 12 for BVH scenes whose persistent waves follow whole
+ *     paths, see PT_TUNE_WAVEFRONT_WHOLE_PATHS; up to about 6.7 GB, allocated on first use -- see
  *     pt_memory_footprint and pt_set_memory_limit).  A render of more iterations
  *     than fit runs as batches that alternate between two buffer sets on two streams (the
  *     caller's and one of the instance's), so that one batch's launches fill the chip while the
@@ -208,11 +209,11 @@ int pt_set_kernel_variant(pt_handle h, int variant);
  *   PT_TUNE_WAVEFRONT_WHOLE_PATHS  BVH scenes, how bounces map to launches: 0: one launch per
  *                              bounce over two queues (100 bytes per path in flight); 2: the
  *                              camera rays in a launch of their own, then one launch that follows
- *                              every surviving path to its end (one queue, 56 bytes; 4 % slower on
- *                              the 10 007-sphere scene); 1: one launch follows every path from its
- *                              camera ray on (no queue, 12 bytes; 6 % slower); -1 (default): 0, or
- *                              the fullest of 2 and 1 whose buffers for one iteration fit the
- *                              memory limit (kept across variant changes) */
+ *                              every surviving path to its end (one queue, 56 bytes; a third of the
+ *                              memory traffic, 0.7 % slower on the 10 007-sphere scene); 1: one
+ *                              launch follows every path from its camera ray on (no queue, 12
+ *                              bytes; 5 % slower); -1 (default): 2, or 1 when the memory limit has no
+ *                              room for one iteration's queue (kept across variant changes) */
 enum { PT_TUNE_REGEN_MIN_IDLE = 0, PT_TUNE_CAMERA_RAY_RING = 1, PT_TUNE_STEAL_UNIT = 2, PT_TUNE_ITERATION_RANGES = 3,
        PT_TUNE_WAVEFRONT_REFILL = 4, PT_TUNE_BVH_NODE_STEPS = 5, PT_TUNE_BVH_STACK = 6, PT_TUNE_WAVEFRONT_BATCH = 7,
        PT_TUNE_WAVEFRONT_WHOLE_PATHS = 8, PT_TUNE_POOL_ITERATIONS = 9 };

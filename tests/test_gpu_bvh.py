@@ -309,7 +309,7 @@ def test_two_buffer_sets_respect_the_callers_stream(pt, torch_cuda):
     tr.Release()
     tr = pt.Pathtracer(cam, 6, 3)
     tr.Init(mats, sph, lights)
-    tr.SetMemoryLimit(2 * 100 * 320 * 200 * 4 + 2**20)             # two sets of one iteration each: seven batches
+    tr.SetMemoryLimit(2 * 56 * 320 * 200 * 4 + 2**20)              # two sets of one iteration each: seven batches
     side = torch.cuda.Stream()
     tr.SetStream(side.cuda_stream)
     buf = torch.full((320 * 200 * 3,), 123.0, device="cuda")
@@ -341,7 +341,7 @@ def test_row_bands_through_the_wavefront_launches(pt, torch_cuda):
     tr.ResetCounters()
     ref = render(torch, tr, 1, 3)
     ref_rays = tr.RayCount()
-    assert tr.LastLaunch() == pt.LAUNCH_WAVEFRONT
+    assert tr.LastLaunch() == pt.LAUNCH_WAVEFRONT_WHOLE_PATHS
     for world in (3, 8):
         total = torch.zeros_like(ref)
         rays = 0
@@ -350,7 +350,7 @@ def test_row_bands_through_the_wavefront_launches(pt, torch_cuda):
             tr.ResetCounters()
             part = render(torch, tr, 1, 3)
             if rank * 16 < 107:      # with 8 ranks the last one owns no band of this frame
-                assert tr.LastLaunch() == pt.LAUNCH_WAVEFRONT
+                assert tr.LastLaunch() == pt.LAUNCH_WAVEFRONT_WHOLE_PATHS
             rays += tr.RayCount()
             total += part
         assert total.cpu().numpy().tobytes() == ref.cpu().numpy().tobytes(), world

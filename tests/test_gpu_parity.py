@@ -742,30 +742,31 @@ def test_variants_tuning_and_memory_footprint(pt, torch_cuda):
     big.Release()
     tr.Release()
 
-    # BVH scene: PT_VARIANT_AUTO takes the wavefront queues, 100 bytes per path of a batch
+    # BVH scene: PT_VARIANT_AUTO takes the persistent BVH waves -- the camera rays in a launch of
+    # their own, then one launch that follows the survivors to their end: one queue of 44-byte
+    # records + 12 bytes of radiance per path of a batch
     mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_SYNTH10K, 1)
     cam = pt.Camera(eye, look, up, 256, 128, 0, 0, fov)
     tr = pt.Pathtracer(cam, 8, 1)
     tr.Init(mats, sph, lights)
     now, nxt = tr.MemoryFootprint(2)
-    paths = 256 * 128 * 4 * 2
-    assert 100 * paths <= nxt - now <= 100 * paths + 2**20
-    ref = render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes()
-    assert tr.MemoryFootprint(2) == (nxt, nxt)
-    tr.Release()
-    tr = pt.Pathtracer(cam, 8, 1)
-    tr.Init(mats, sph, lights)
     ppi = 256 * 128 * 4
-    tr.SetMemoryLimit(100 * ppi - 1)                               # no room for one iteration's two queues:
-    now, nxt = tr.MemoryFootprint(2)                               # camera rays, then whole paths; one queue, 56 bytes
-    assert 56 * ppi <= nxt - now <= 56 * ppi + 2**20               # one iteration per batch
+    paths = ppi * 2
+    assert 56 * paths <= nxt - now <= 56 * paths + 2**20
+    ref = render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes()
+    assert tr.LastLaunch() == pt.LAUNCH_WAVEFRONT_WHOLE_PATHS
+    assert tr.MemoryFootprint(2) == (nxt, nxt)
+    tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, 0)                 # one launch per bounce: two queues, 100 bytes
+    now, nxt = tr.MemoryFootprint(2)
+    assert 44 * paths <= nxt - now <= 44 * paths + 2**20           # the second queue
     assert render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes() == ref
+    assert tr.LastLaunch() == pt.LAUNCH_WAVEFRONT
     assert tr.MemoryFootprint(2) == (nxt, nxt)
     tr.Release()
     tr = pt.Pathtracer(cam, 8, 1)
     tr.Init(mats, sph, lights)
-    tr.SetMemoryLimit(56 * ppi - 1)                                # nor for one queue: whole paths from the camera ray on,
-    now, nxt = tr.MemoryFootprint(2)                               # 12 bytes per path, both iterations in one batch
+    tr.SetMemoryLimit(56 * ppi - 1)                                # no room for one iteration's queue: whole paths from
+    now, nxt = tr.MemoryFootprint(2)                               # the camera ray on, 12 bytes per path, one batch
     assert 12 * paths <= nxt - now <= 12 * paths + 2**20
     assert render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes() == ref
     assert tr.MemoryFootprint(2) == (nxt, nxt)
@@ -781,7 +782,7 @@ def test_variants_tuning_and_memory_footprint(pt, torch_cuda):
     with pytest.raises(pt.PtError) as e:
         tr.RunN(torch_cuda.zeros(256 * 128 * 3, device="cuda"), 1)
     assert e.value.code == pt.PT_ERR_NOMEM
-    tr.SetMemoryLimit(100 * 256 * 128 * 4 + 2**20)                 # one iteration per batch
+    tr.SetMemoryLimit(56 * 256 * 128 * 4 + 2**20)                  # one iteration per batch
     tr.SetKernelVariant(pt.VARIANT_AUTO)
     assert render(torch_cuda, tr, 1, 2).cpu().numpy().tobytes() == ref
     # room for two iterations: two buffer sets of one iteration each, batches alternating between
@@ -791,9 +792,9 @@ def test_variants_tuning_and_memory_footprint(pt, torch_cuda):
     tr.Release()
     tr = pt.Pathtracer(cam, 8, 1)
     tr.Init(mats, sph, lights)
-    tr.SetMemoryLimit(2 * 100 * 256 * 128 * 4 + 2**20)
+    tr.SetMemoryLimit(2 * 56 * 256 * 128 * 4 + 2**20)
     now, nxt = tr.MemoryFootprint(5)
-    assert 2 * 100 * 256 * 128 * 4 <= nxt - now <= 2 * 100 * 256 * 128 * 4 + 2**20
+    assert 2 * 56 * 256 * 128 * 4 <= nxt - now <= 2 * 56 * 256 * 128 * 4 + 2**20
     assert render(torch_cuda, tr, 1, 5).cpu().numpy().tobytes() == ref5
     assert tr.MemoryFootprint(5) == (nxt, nxt)
     tr.SetTuning(pt.TUNE_WAVEFRONT_BATCH, 1)                       # 2^20 paths in flight: eight iterations, four per set
