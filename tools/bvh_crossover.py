@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Where does the sphere BVH start to beat the linear scan?  Renders clouds of n small spheres in
 the demo room at 1080p with both (PT_ACCEL_AUTO / PT_ACCEL_BRUTE_FORCE) and prints the times.
-Scenes of up to 512 spheres never get a BVH (they are scanned from LDS), so only n > 512 is
-informative; run on the GPU box:  python tools/bvh_crossover.py"""
+The library builds a BVH above kBvhMinSpheres spheres only; to look below that, build a copy with
+a lower constant and point PT_LIB at it.  Run on the GPU box:  python tools/bvh_crossover.py"""
 import importlib
 import os
 import sys
@@ -12,6 +12,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pt = importlib.import_module("cuda-pathtracer_amd")
+if os.environ.get("PT_LIB"):      # another build of the library
+    pt.LIB_PATH = os.path.abspath(os.environ["PT_LIB"])
 
 
 def main():
@@ -19,7 +21,7 @@ def main():
     cam = pt.Camera(eye, look, up, 1920, 1080, 0, 0, fov)
     buf = torch.zeros(1920 * 1080 * 3, device="cuda")
     rng = np.random.default_rng(1)
-    for n in (40, 64, 100, 160, 250, 400, 520, 1000, 5000, 20000, 100000):
+    for n in [int(a) for a in sys.argv[1:]] or (40, 64, 100, 160, 250, 400, 520, 1000, 5000, 20000, 100000):
         extra = np.zeros(n, pt.SPHERE_DTYPE)
         extra["pos"] = np.column_stack([rng.uniform(-45, 45, n), rng.uniform(5, 75, n), rng.uniform(-75, 20, n)])
         extra["radius"] = rng.uniform(0.3, 1.2, n) * (10000 / n) ** (1 / 3)   # same volume fraction
@@ -27,7 +29,7 @@ def main():
         extra["light_id"] = -1
         scene = np.concatenate([sph, extra])
         row = [f"n={n + len(sph):7d}"]
-        for accel, variant, label in ((pt.ACCEL_BRUTE_FORCE, 0, "scan"), (pt.ACCEL_AUTO, 0, "bvh megakernel"),
+        for accel, variant, label in ((pt.ACCEL_BRUTE_FORCE, -1, "scan"), (pt.ACCEL_AUTO, 0, "bvh megakernel"),
                                       (pt.ACCEL_AUTO, -1, "bvh auto")):
             if accel == pt.ACCEL_BRUTE_FORCE and n > 20000:
                 continue
@@ -35,7 +37,7 @@ def main():
             tr.Init(mats, scene, lights)
             tr.SetAccel(accel)
             tr.SetKernelVariant(variant)
-            its = 2
+            its = 4
             tr.RunN(buf, its)            # warm-up (allocates the queues)
             tr.Reset(); tr.ResetCounters()
             tr.RunN(buf, its)
