@@ -94,11 +94,15 @@ def main():
         ref_trace = tr.DebugTrace(0, 0, 96, 64, 1)
         if tr.AccelNodes() > 0:
             n_bvh += 1
-            for variant in (0, 100, 101):
+            # the BVH megakernel, the persistent waves (default launch structure), static chunks,
+            # PT_VARIANT_AUTO, and the other two mappings of bounces to launches
+            for variant, mode in ((0, -1), (100, -1), (101, -1), (-1, -1), (-1, 0), (-1, 1)):
+                tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, mode)
                 got = render(tr, buf, pt.ACCEL_AUTO, variant)
                 if got != ref:
-                    print(f"MISMATCH seed {seed} variant {variant}: {len(sph)} spheres, rays {got[1]} vs {ref[1]}")
+                    print(f"MISMATCH seed {seed} variant {variant} launches {mode}: {len(sph)} spheres, rays {got[1]} vs {ref[1]}")
                     return 1
+            tr.SetTuning(pt.TUNE_WAVEFRONT_WHOLE_PATHS, -1)
             tr.SetKernelVariant(0)
             hits, rad, _, _ = tr.DebugTrace(0, 0, 96, 64, 1)
             if not np.array_equal(hits, ref_trace[0]) or rad.tobytes() != ref_trace[1].tobytes():
