@@ -805,6 +805,8 @@ static uint32_t wavefront_batch_iterations(const pt_context *h, int mode, uint64
         if (batch_it < 1) batch_it = h->memory_limit ? 0 : 1;
     }
     if (batch_it > n_iterations) batch_it = n_iterations;
+    // the kernels number the paths of a batch with 32 bits
+    if (batch_it > 0xffffffffull / paths_per_it) batch_it = 0xffffffffull / paths_per_it;
     if (sets) *sets = n_sets;
     return (uint32_t)batch_it;
 }

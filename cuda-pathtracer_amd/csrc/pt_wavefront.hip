@@ -26,6 +26,19 @@ PT_DEV uint32_t *count_ptr(uint32_t *counts, int bounce, uint32_t q)
     return counts + ((size_t)bounce * kWfSubQueues + q) * kWfCountStride;
 }
 
+// a / b through the float reciprocal of b: the estimate is off by at most one while the quotient
+// stays below 2^20 and b below 2^30 (row, band and iteration numbers; the compiler's exact
+// division is some 25 instructions, 64-bit operands more), `rem` gets a - q * b.
+PT_DEV uint32_t div_small(uint32_t a, uint32_t b, uint32_t &rem)
+{
+    uint32_t q = (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b));
+    int32_t r = (int32_t)(a - q * b);
+    if (r < 0) { --q; r += (int32_t)b; }
+    else if (r >= (int32_t)b) { ++q; r -= (int32_t)b; }
+    rem = (uint32_t)r;
+    return q;
+}
+
 // The batch covers the pixel rectangle [x0, x0 + rect_w) x [y0, y0 + rect_h) (the whole frame for a
 // render, a part of it for the parity hook).  Paths are numbered over the rectangle's pixels in
 // row-major order; a path carries its frame-wide pixel index (the Philox counter).
@@ -33,12 +46,14 @@ PT_DEV uint32_t *count_ptr(uint32_t *counts, int bounce, uint32_t q)
 // this instance owns, band after band: bands b with b % band_world == band_rank.
 PT_DEV uint32_t rect_to_frame(const WavefrontParams &p, uint32_t local, uint32_t &x, uint32_t &y)
 {
-    const uint32_t ry = local / p.rect_w;
-    x = p.x0 + (local - ry * p.rect_w);
+    uint32_t rx;
+    const uint32_t ry = div_small(local, p.rect_w, rx);
+    x = p.x0 + rx;
     y = p.y0 + ry;
     if (p.band_world > 1u) {
-        const uint32_t band = ry / p.band_rows;
-        y = (band * p.band_world + p.band_rank) * p.band_rows + (ry - band * p.band_rows);
+        uint32_t row_in_band;
+        const uint32_t band = div_small(ry, p.band_rows, row_in_band);
+        y = (band * p.band_world + p.band_rank) * p.band_rows + row_in_band;
     }
     return y * p.cam.width + x;
 }
@@ -46,10 +61,12 @@ PT_DEV uint32_t rect_to_frame(const WavefrontParams &p, uint32_t local, uint32_t
 PT_DEV uint32_t frame_to_rect(const WavefrontParams &p, uint32_t pix)
 {
     if (p.rect_w == p.cam.width && p.x0 == 0u && p.y0 == 0u && p.band_world <= 1u) return pix;   // wave-uniform
-    const uint32_t y = pix / p.cam.width, x = pix - y * p.cam.width;
+    uint32_t x;
+    const uint32_t y = div_small(pix, p.cam.width, x);
     if (p.band_world > 1u) {
-        const uint32_t period = p.band_rows * p.band_world, k = y / period;
-        return (k * p.band_rows + (y - k * period - p.band_rank * p.band_rows)) * p.rect_w + x;
+        uint32_t row_in_period;
+        const uint32_t k = div_small(y, p.band_rows * p.band_world, row_in_period);
+        return (k * p.band_rows + (row_in_period - p.band_rank * p.band_rows)) * p.rect_w + x;
     }
     return (y - p.y0) * p.rect_w + (x - p.x0);
 }
@@ -115,9 +132,9 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
             if (active) {
                 const uint32_t sub = (uint32_t)(i & 3);
                 const uint64_t ip = i >> 2;
-                const uint32_t it_off = (uint32_t)(ip / n_pix);
-                uint32_t x, y;
-                pix = rect_to_frame(p, (uint32_t)(ip - (uint64_t)it_off * n_pix), x, y);
+                uint32_t local, x, y;
+                const uint32_t it_off = div_small((uint32_t)ip, n_pix, local);   // a batch holds fewer than 2^32 paths
+                pix = rect_to_frame(p, local, x, y);
                 it_sub = ((p.first_iteration + it_off) << 2) | sub;
                 d = camera_ray(p.cam, x, y, pix, it_sub >> 2, (int)sub, k0, k1);
             }
@@ -249,9 +266,9 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
                     if (i < n_paths) {
                         const uint32_t sub = (uint32_t)(i & 3);
                         const uint64_t ip = i >> 2;
-                        const uint32_t it_off = (uint32_t)(ip / n_pix);
-                        uint32_t x, y;
-                        pix = rect_to_frame(p, (uint32_t)(ip - (uint64_t)it_off * n_pix), x, y);
+                        uint32_t local, x, y;
+                        const uint32_t it_off = div_small((uint32_t)ip, n_pix, local);
+                        pix = rect_to_frame(p, local, x, y);
                         it_sub = ((p.first_iteration + it_off) << 2) | sub;
                         o = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
                         d = camera_ray(p.cam, x, y, pix, it_sub >> 2, (int)sub, k0, k1);
@@ -396,9 +413,9 @@ __global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontP
                 if (valid) {
                     const uint32_t sub = (uint32_t)(i & 3);
                     const uint64_t ip = i >> 2;
-                    const uint32_t it_off = (uint32_t)(ip / n_pix);
-                    uint32_t x, y;
-                    e.pix = rect_to_frame(p, (uint32_t)(ip - (uint64_t)it_off * n_pix), x, y);
+                    uint32_t local, x, y;
+                    const uint32_t it_off = div_small((uint32_t)ip, n_pix, local);
+                    e.pix = rect_to_frame(p, local, x, y);
                     e.it_sub = ((p.first_iteration + it_off) << 2) | sub;
                     const V3 dir = camera_ray(p.cam, x, y, e.pix, e.it_sub >> 2, (int)sub, k0, k1);
                     e.dx = dir.x; e.dy = dir.y; e.dz = dir.z;
