@@ -671,7 +671,7 @@ int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
     const uint64_t paths_per_it = (uint64_t)h->camera.width * owned_rows(h) * 4;
     uint32_t wf_sets = 1;
     const int wf_mode = wavefront_mode(h, n_iterations);
-    const uint32_t batch_it = n_iterations ? wavefront_batch_iterations(h, wf_mode, paths_per_it, n_iterations, &wf_sets) : 0;
+    const uint32_t batch_it = n_iterations && paths_per_it ? wavefront_batch_iterations(h, wf_mode, paths_per_it, n_iterations, &wf_sets) : 0;
     if (n_iterations && h->scene_ready && paths_per_it && takes_wavefront(h, h->iteration + (uint64_t)n_iterations, n_iterations) && batch_it > 0) {
         const uint64_t capacity = paths_per_it * batch_it;
         const uint64_t sub_cap = wavefront_sub_capacity(h->camera.width, owned_rows(h), batch_it);
@@ -945,7 +945,10 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
         p.overwrite = h->accum_mode == PT_ACCUM_RUNNING_MEAN ? (p.first_iteration == 1)
                                                              : ((h->fresh && done == 0) ? 1 : 0);
         const int brc = launch_wavefront_batch(h, p, mode, counts_bytes, set, set ? h->wf_stream2 : h->stream, before);
-        if (brc != PT_OK) return brc;
+        if (brc != PT_OK) {   // nothing of this call may still run on the second stream when the caller sees the error
+            if (sets > 1) (void)hipStreamSynchronize(h->wf_stream2);
+            return brc;
+        }
         before = h->wf_pipe[set].resolved;
         done += n;
         if (sets > 1) set ^= 1;

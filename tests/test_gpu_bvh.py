@@ -348,6 +348,7 @@ def test_row_bands_through_the_wavefront_launches(pt, torch_cuda):
         for rank in range(world):
             tr.SetRowBands(16, rank, world)
             tr.ResetCounters()
+            assert tr.MemoryFootprint(3)[1] >= tr.MemoryFootprint(3)[0]   # also for a rank without a band
             part = render(torch, tr, 1, 3)
             if rank * 16 < 107:      # with 8 ranks the last one owns no band of this frame
                 assert tr.LastLaunch() == pt.LAUNCH_WAVEFRONT_WHOLE_PATHS
