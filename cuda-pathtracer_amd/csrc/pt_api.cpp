@@ -71,6 +71,7 @@ struct pt_context {
         float *radiance;
         uint32_t *counts;
         hipEvent_t resolved;    // recorded after the set's resolve kernel
+        bool counts_dirty;      // the counters are not known to be zero (fresh allocation, failed batch)
     } wf_pipe[2];
     hipStream_t wf_stream2;
     hipEvent_t wf_fork;
@@ -842,6 +843,7 @@ static int ensure_wavefront(pt_context *h, int mode, uint64_t capacity, uint64_t
             ok = ok && hipMalloc((void **)&pipe.radiance, capacity * 3 * sizeof(float)) == hipSuccess &&
                  hipMalloc((void **)&pipe.counts, counts_bytes) == hipSuccess &&
                  hipEventCreateWithFlags(&pipe.resolved, hipEventDisableTiming) == hipSuccess;
+            pipe.counts_dirty = true;
         }
         if (!ok) {
             (void)hipGetLastError();
@@ -878,7 +880,9 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, int mode, s
     pt_context::WfPipe &pipe = h->wf_pipe[set];
     p.counts = pipe.counts;
     p.path_radiance = pipe.radiance;
-    PT_HIP(h, hipMemsetAsync(pipe.counts, 0, counts_bytes, stream));
+    // the resolve kernel leaves the counters at zero for the set's next batch
+    if (pipe.counts_dirty) PT_HIP(h, hipMemsetAsync(pipe.counts, 0, counts_bytes, stream));
+    pipe.counts_dirty = true;
     if (mode != 3) {   // the queue-fed kernels add to the path's entry bounce by bounce; the path pool stores it once
         const uint64_t batch_paths = (uint64_t)p.n_iterations * p.rect_w * p.rect_h * 4;
         PT_HIP(h, hipMemsetAsync(pipe.radiance, 0, batch_paths * 3 * sizeof(float), stream));
@@ -894,6 +898,7 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, int mode, s
     }
     if (after) PT_HIP(h, hipStreamWaitEvent(stream, after, 0));
     PT_HIP(h, launch_wavefront_resolve(p, stream));
+    pipe.counts_dirty = false;
     PT_HIP(h, hipEventRecord(pipe.resolved, stream));
     return PT_OK;
 }

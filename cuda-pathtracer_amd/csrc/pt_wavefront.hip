@@ -493,12 +493,17 @@ __global__ __launch_bounds__(kBlockThreads) void wf_resolve_kernel(const Wavefro
             pr[0] = cpix.x; pr[1] = cpix.y; pr[2] = cpix.z;
         }
     }
-    // Intersect calls of the batch = paths entering each bounce
-    if (blockIdx.x == 0 && threadIdx.x < kWfSubQueues && p.ray_counter) {
+    // Intersect calls of the batch = paths entering each bounce.  The counters and cursors are left
+    // at zero for the buffer set's next batch (every launch of this batch has finished: stream order).
+    if (blockIdx.x == 0 && threadIdx.x < kWfSubQueues) {
         unsigned long long n = 0;
-        for (int b = 1; b <= p.max_bounces; ++b) n += *count_ptr(p.counts, b, threadIdx.x);
+        for (int b = 0; b <= p.max_bounces + 1; ++b) {
+            uint32_t *c = count_ptr(p.counts, b, threadIdx.x);
+            if (b >= 1 && b <= p.max_bounces) n += c[0];
+            c[0] = 0u; c[1] = 0u;
+        }
         if (threadIdx.x == 0) n += (unsigned long long)p.n_iterations * n_pix * 4;
-        atomicAdd(p.ray_counter, n);
+        if (p.ray_counter) atomicAdd(p.ray_counter, n);
     }
 }
 
