@@ -874,7 +874,7 @@ static void fill_wavefront(const pt_context *h, WavefrontParams &p)
 // the resolve -- after the resolve of the batch before (`after`, the other set's event, or null):
 // the frame buffer takes the batches' iterations in order.
 static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, int mode, size_t counts_bytes, int set, hipStream_t stream,
-                                  hipEvent_t after)
+                                  hipEvent_t after, bool record = true)
 {
     const bool tiled = scene_streams(p.scene);
     pt_context::WfPipe &pipe = h->wf_pipe[set];
@@ -899,7 +899,7 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, int mode, s
     if (after) PT_HIP(h, hipStreamWaitEvent(stream, after, 0));
     PT_HIP(h, launch_wavefront_resolve(p, stream));
     pipe.counts_dirty = false;
-    PT_HIP(h, hipEventRecord(pipe.resolved, stream));
+    if (record) PT_HIP(h, hipEventRecord(pipe.resolved, stream));   // for the other set's next resolve
     return PT_OK;
 }
 
@@ -949,17 +949,17 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
         p.n_iterations = n;
         p.overwrite = h->accum_mode == PT_ACCUM_RUNNING_MEAN ? (p.first_iteration == 1)
                                                              : ((h->fresh && done == 0) ? 1 : 0);
-        const int brc = launch_wavefront_batch(h, p, mode, counts_bytes, set, set ? h->wf_stream2 : h->stream, before);
+        const int brc = launch_wavefront_batch(h, p, mode, counts_bytes, set, set ? h->wf_stream2 : h->stream, before, sets > 1);
         if (brc != PT_OK) {   // nothing of this call may still run on the second stream when the caller sees the error
             if (sets > 1) (void)hipStreamSynchronize(h->wf_stream2);
             return brc;
         }
-        before = h->wf_pipe[set].resolved;
+        before = sets > 1 ? h->wf_pipe[set].resolved : nullptr;
         done += n;
         if (sets > 1) set ^= 1;
     }
     // the caller's stream ends behind the last resolve (its own, which waited for the other's, or the other's)
-    if (before == h->wf_pipe[1].resolved) PT_HIP(h, hipStreamWaitEvent(h->stream, before, 0));
+    if (before && before == h->wf_pipe[1].resolved) PT_HIP(h, hipStreamWaitEvent(h->stream, before, 0));
     PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
     h->timed = true;
     h->last_launch = mode == 3 ? PT_LAUNCH_PATH_POOL : mode == 0 ? PT_LAUNCH_WAVEFRONT : PT_LAUNCH_WAVEFRONT_WHOLE_PATHS;
