@@ -80,6 +80,7 @@ ABI = [
     ("pt_accel_stats", _i32, [_vp, _pu64]),
     ("pt_lane_stats", _i32, [_vp, _pu64]),
     ("pt_debug_build_bvh", _i32, [_vp, _u32, _pu32, _vp, _vp, _vp]),
+    ("pt_debug_plan_batches", _i32, [_u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _pu32]),
     ("pt_last_kernel_ms", _i32, [_vp, _pf]),
     ("pt_last_launch", _i32, [_vp, ctypes.POINTER(ctypes.c_int)]),
     ("pt_read_image", _i32, [_vp, _vp, _vp]),
@@ -217,6 +218,17 @@ def build_scene(scene_id: int = SCENE_DEMO, seed: int = 1):
     if rc != PT_OK:
         raise PtError(rc, "pt_scene_build failed")
     return mats, sph, lights, (eye, look_at, up, float(fov.value))
+
+
+def debug_plan_batches(width, height, n_iterations, bytes_per_path, memory_limit=0, bands=None):
+    """(rows owned, iterations per batch, buffer sets, slots per sub-queue) -- the host-side batch
+    planner of the path pool / wavefront variant; bands = (band_rows, rank, world).  No device needed."""
+    lib = load_library()
+    out = (_u32 * 4)()
+    band_rows, rank, world = bands if bands else (0, 0, 1)
+    if lib.pt_debug_plan_batches(width, height, band_rows, rank, world, n_iterations, bytes_per_path, memory_limit, out) != PT_OK:
+        raise ValueError("pt_debug_plan_batches: invalid arguments")
+    return tuple(int(v) for v in out)
 
 
 def debug_build_bvh(spheres):

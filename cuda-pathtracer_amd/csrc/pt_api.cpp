@@ -627,15 +627,17 @@ static uint32_t wavefront_batch_iterations(const pt_context *h, int mode, uint64
 static int wavefront_mode(const pt_context *h, uint32_t n_iterations);
 static bool takes_wavefront(const pt_context *h, uint64_t last_iteration, uint32_t n_iterations);
 static int wavefront_whole_paths(const pt_context *h);
-// Rows of the frame this instance renders: all of them, or those of its row bands.
-static uint32_t owned_rows(const pt_context *h)
+// Rows of a frame of `height` rows an instance renders: all of them, or those of its row bands
+// (bands of band_rows rows, band b to rank b % world).
+static uint32_t owned_rows(uint32_t height, uint32_t band_rows, uint32_t rank, uint32_t world)
 {
-    if (h->band_world <= 1) return h->camera.height;
+    if (world <= 1) return height;
     uint32_t rows = 0;
-    for (uint32_t y = h->band_rank * h->band_rows; y < h->camera.height; y += h->band_rows * h->band_world)
-        rows += h->camera.height - y < h->band_rows ? h->camera.height - y : h->band_rows;
+    for (uint64_t y = (uint64_t)rank * band_rows; y < height; y += (uint64_t)band_rows * world)
+        rows += height - y < band_rows ? (uint32_t)(height - y) : band_rows;
     return rows;
 }
+static uint32_t owned_rows(const pt_context *h) { return owned_rows(h->camera.height, h->band_rows, h->band_rank, h->band_world); }
 
 // Slots per sub-queue for a batch of `iterations` iterations over a w x h rectangle: the batch is
 // dealt out in blocks of 256 paths, block k to sub-queue k % 64, and a sub-queue keeps its survivors.
@@ -793,23 +795,45 @@ static uint64_t wavefront_bytes_per_path(int mode)
 // handle's memory limit; 0 when not even one iteration fits.  A render of more iterations than
 // that runs as several batches alternating between two buffer sets of half the size each
 // (*sets = 2); when half the memory does not hold one iteration, one set takes all of it.
-static uint32_t wavefront_batch_iterations(const pt_context *h, int mode, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets = nullptr)
+static uint32_t plan_batches(uint64_t paths_per_it, uint32_t n_iterations, uint64_t per_path, uint64_t memory_limit,
+                             uint32_t target_mpaths, uint32_t *sets)
 {
-    const uint64_t per_path = wavefront_bytes_per_path(mode);
-    uint64_t target = h->wf_target_mpaths ? (uint64_t)h->wf_target_mpaths << 20 : kWfTargetBytes / per_path;
-    if (h->memory_limit && h->memory_limit / per_path < target) target = h->memory_limit / per_path;
+    uint64_t target = target_mpaths ? (uint64_t)target_mpaths << 20 : kWfTargetBytes / per_path;
+    if (memory_limit && memory_limit / per_path < target) target = memory_limit / per_path;
     uint32_t n_sets = 2;
     uint64_t batch_it = target / 2 / paths_per_it;
     if (batch_it < 1 || batch_it >= n_iterations) {
         n_sets = 1;
         batch_it = batch_it < 1 ? target / paths_per_it : batch_it;
-        if (batch_it < 1) batch_it = h->memory_limit ? 0 : 1;
+        if (batch_it < 1) batch_it = memory_limit ? 0 : 1;
     }
     if (batch_it > n_iterations) batch_it = n_iterations;
     // the kernels number the paths of a batch with 32 bits
     if (batch_it > 0xffffffffull / paths_per_it) batch_it = 0xffffffffull / paths_per_it;
     if (sets) *sets = n_sets;
     return (uint32_t)batch_it;
+}
+
+static uint32_t wavefront_batch_iterations(const pt_context *h, int mode, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets = nullptr)
+{
+    return plan_batches(paths_per_it, n_iterations, wavefront_bytes_per_path(mode), h->memory_limit, h->wf_target_mpaths, sets);
+}
+
+int pt_debug_plan_batches(uint32_t width, uint32_t height, uint32_t band_rows, uint32_t band_rank, uint32_t band_world,
+                          uint32_t n_iterations, uint32_t bytes_per_path, uint64_t memory_limit, uint32_t out[4])
+{
+    if (!out || !width || !height || !bytes_per_path || (band_world > 1 && (!band_rows || band_rank >= band_world)))
+        return PT_ERR_INVALID;
+    const uint32_t rows = owned_rows(height, band_rows, band_rank, band_world);
+    const uint64_t paths_per_it = (uint64_t)width * rows * 4;
+    uint32_t sets = 1;
+    const uint32_t batch_it = paths_per_it && n_iterations ? plan_batches(paths_per_it, n_iterations, bytes_per_path, memory_limit, 0, &sets) : 0;
+    out[0] = rows;
+    out[1] = batch_it;
+    out[2] = batch_it ? sets : 0;
+    const uint64_t sub_cap = batch_it ? wavefront_sub_capacity(width, rows, batch_it) : 0;
+    out[3] = sub_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)sub_cap;
+    return PT_OK;
 }
 
 // `sets` sets of queues, per-path radiance and counters for batches of `capacity` paths (kept while

@@ -265,6 +265,14 @@ int pt_set_accel_budget(pt_handle h, uint32_t visits);
  * [always-tested].  Call once to size, once to fill. */
 int pt_debug_build_bvh(const pt_sphere *spheres, uint32_t n_spheres, uint32_t counts[4], float *nodes,
                        int32_t *leaf_index, int32_t *big_index);
+/* Test hook, host only (no device needed): how a render of n_iterations over a width x height
+ * frame is cut into batches by the path pool and the wavefront variant, with row bands
+ * (band_world <= 1: none) and bytes_per_path of buffers per path in flight (12, 56 or 100) under
+ * memory_limit (0: the default budget).  out = {rows this rank owns, iterations per batch (0: not
+ * one iteration fits), buffer sets (1 or 2; batches alternate between them), slots per
+ * sub-queue}. */
+int pt_debug_plan_batches(uint32_t width, uint32_t height, uint32_t band_rows, uint32_t band_rank, uint32_t band_world,
+                          uint32_t n_iterations, uint32_t bytes_per_path, uint64_t memory_limit, uint32_t out[4]);
 /* Traversal counters since the last call (only libraries built with -DPT_BVH_STATS count -- the
  * counting costs time -- others return zeros):
  *   [0] inner nodes visited  [1] leaves visited  [2] rays traversed  [3] rays finished by the wave-wide scan
