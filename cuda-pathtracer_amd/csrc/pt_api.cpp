@@ -768,14 +768,14 @@ static int wavefront_whole_paths(const pt_context *h)
     return 2;
 }
 
-// Launches of a few iterations over a scene that is rendered by the linear scan from LDS: the
-// path pool (wf_pool_kernel) instead of the megakernel, whose lanes own pixels.
+// Launches over a scene that is rendered by the linear scan (resident in LDS or streamed through
+// it in tiles): the path pool (wf_pool_kernel) instead of the megakernel, whose lanes own pixels.
 static bool takes_pool(const pt_context *h, uint64_t last_iteration, uint32_t n_iterations)
 {
     SceneParams s;
     fill_scene(h, s);
     return h->auto_variant && h->integrator == PT_INTEGRATOR_PATH && s.bvh.n_nodes == 0 &&
-           !scene_streams(s) && n_iterations > 0 && n_iterations <= (uint32_t)h->pool_max_iterations &&
+           n_iterations > 0 && n_iterations <= (uint32_t)h->pool_max_iterations &&
            last_iteration < (1u << 30);
 }
 

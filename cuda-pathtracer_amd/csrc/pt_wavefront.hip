@@ -369,9 +369,14 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
 // generates 64 camera rays at a time with all lanes active (paths of the batch in the order of
 // the static kernel's bounce 0, 64 consecutive items of the workgroup's sub-queue per refill) into
 // a ring of 128 entries in LDS, idle lanes pop.
+//
+// TILED: scenes of more than 512 spheres rendered without the BVH, whose spheres pass through LDS
+// one tile at a time.  The tile loads are workgroup barriers, so the four waves make their passes
+// together: a wave whose pool has run dry keeps loading tiles until the other three are done too.
 constexpr uint32_t kPoolRing = 128;
 struct PoolEntry { float dx, dy, dz; uint32_t pix, it_sub; };
 
+template <bool TILED>
 __global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -385,8 +390,9 @@ __global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontP
     if (blockIdx.y * (uint32_t)kBlockThreads >= n_items) return;   // uniform for the workgroup
     uint32_t *cursor = count_ptr(p.counts, 0, q) + 1;
 
-    const SceneView sc = stage_scene<false>(p.scene, lds_raw, tid);
-    PoolEntry *ring = reinterpret_cast<PoolEntry *>(lds_raw + scene_lds_bytes_dev(p.scene)) + (tid >> 6) * kPoolRing;
+    const SceneView sc = stage_scene<TILED>(p.scene, lds_raw, tid);
+    const uint32_t scene_bytes = TILED ? kTileSpheres * (uint32_t)sizeof(float4) : scene_lds_bytes_dev(p.scene);
+    PoolEntry *ring = reinterpret_cast<PoolEntry *>(lds_raw + scene_bytes) + (tid >> 6) * kPoolRing;
     const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
 
     uint32_t head = 0, count = 0;          // the wave's ring (wave-uniform)
@@ -443,19 +449,22 @@ __global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontP
             count -= taken;
             __builtin_amdgcn_wave_barrier();
         }
-        if (!__any(has)) {
+        if (TILED) {
+            // all four waves leave together (barriers in the scan)
+            if (__syncthreads_and(!__any(has) && exhausted && count == 0)) break;
+        } else if (!__any(has)) {
             if (exhausted && count == 0) break;
             continue;   // a refill brought no valid item yet (the batch's last, partly empty block)
         }
 
         float tmax;
         int best;
-        intersect_scene<false, false>(p.scene, sc, lds_raw, tid, has, o, d, tmax, best);
+        intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, has, o, d, tmax, best);
         bool cont = false;
         if (has) {
             bool end = true;
             record_hit(p, n_pix, pix, it_sub, b, best);
-            if (best >= 0) end = shade_bounce(sc, sc.sph[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
+            if (best >= 0) end = shade_bounce(sc, (TILED ? p.scene.sph : sc.sph)[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
             if (end) {   // the path lived in this lane from its camera ray on: one store, no zeroed buffer needed
                 float *pr = p.path_radiance + batch_path_index(p, n_pix, pix, it_sub) * 3;
                 pr[0] = L.x; pr[1] = L.y; pr[2] = L.z;
@@ -548,16 +557,17 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
     const uint32_t chunks = p.sub_capacity / kBlockThreads;
     const dim3 grid(kWfSubQueues, chunks < 32u ? chunks : 32u), block(kBlockThreads);
     const bool bvh = p.scene.bvh.n_nodes > 0;   // BVH kernels read the scene from global memory
-    if (p.path_pool && !bvh && !tiled) {
+    if (p.path_pool && !bvh) {
         // one resident set of persistent workgroups: 8 per CU (8 waves per SIMD), fewer if LDS says so
-        const size_t pool_lds = scene_lds_bytes(p.scene, false) + (kBlockThreads / 64) * kPoolRing * sizeof(PoolEntry);
+        const size_t pool_lds = scene_lds_bytes(p.scene, tiled) + (kBlockThreads / 64) * kPoolRing * sizeof(PoolEntry);
         uint32_t per_cu = (uint32_t)((160u * 1024u) / pool_lds);
         if (per_cu > 8u) per_cu = 8u;
         if (per_cu < 1u) per_cu = 1u;
         const uint32_t rows = (per_cu * (uint32_t)current_device_cus() + kWfSubQueues - 1) / kWfSubQueues;
         const uint32_t pool_chunks = p.sub_capacity / kBlockThreads;
-        hipLaunchKernelGGL(wf_pool_kernel, dim3(kWfSubQueues, pool_chunks < rows ? pool_chunks : rows), dim3(kBlockThreads),
-                           pool_lds, stream, p);
+        const dim3 pool_grid(kWfSubQueues, pool_chunks < rows ? pool_chunks : rows);
+        if (tiled) hipLaunchKernelGGL(wf_pool_kernel<true>, pool_grid, block, pool_lds, stream, p);
+        else       hipLaunchKernelGGL(wf_pool_kernel<false>, pool_grid, block, pool_lds, stream, p);
         return hipGetLastError();
     }
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : scene_lds_bytes(p.scene, tiled);

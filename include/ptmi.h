@@ -158,7 +158,7 @@ int pt_reset_counters(pt_handle h);
 /* Kernel variant; results are bit-identical in all of them.
  *   PT_VARIANT_AUTO (default), when the integrator is PT_INTEGRATOR_PATH and the buffers fit the
  *     memory limit (row bands included: the batch then holds the owned rows only): PT_VARIANT_WAVEFRONT for scenes rendered through the
- *     sphere BVH; the path pool for scenes that fit LDS (up to 512 spheres): persistent waves
+ *     sphere BVH; the path pool for scenes rendered by the linear scan: persistent waves
  *     whose lanes take the next camera ray of the batch, whatever pixel it belongs to, when their
  *     path has ended, 12 bytes of radiance per path in flight folded into the frame in the
  *     reference's order afterwards, batches on two streams like PT_VARIANT_WAVEFRONT's.

@@ -313,7 +313,7 @@ def test_work_stealing_variant_is_bit_exact(pt, O, torch_cuda):
     mats, sph, lights = _random_scene(np.random.default_rng(3), O, 600)
     cam = pt.Camera([0, 45, 79.5], [0, 35, 0], [0, 1, 0], 40, 28, 0, 0, 50.0)
     ref, _, _, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, 8, 6, n_iterations=12)
-    for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING, pt.VARIANT_STEALING + 11):
+    for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING, pt.VARIANT_STEALING + 11, pt.VARIANT_AUTO):
         tr = pt.Pathtracer(cam, 6, 8)
         tr.Init(mats, sph, lights)
         tr.SetAccel(pt.ACCEL_BRUTE_FORCE)
@@ -322,6 +322,8 @@ def test_work_stealing_variant_is_bit_exact(pt, O, torch_cuda):
         buf = render(torch_cuda, tr, 1, 12)
         assert buf.cpu().numpy().tobytes() == ref.tobytes(), variant
         assert tr.RayCount() == ref_rays
+        if variant == pt.VARIANT_AUTO:   # the path pool with the scan's barriers shared by four waves
+            assert tr.LastLaunch() == pt.LAUNCH_PATH_POOL
         tr.Release()
 
     # sum buffer and row bands; 48 iterations on a small image: the default cuts the launch into 3 ranges
