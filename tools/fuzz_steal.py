@@ -45,7 +45,7 @@ def one_case(seed):
     elif kind == 1:
         mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_MIXED, 1)
     else:
-        mats, sph, lights = random_cloud(rng, int(rng.choice([3, 30, 150, 400, 700])))
+        mats, sph, lights = random_cloud(rng, int(rng.choice([3, 30, 150, 400, 700, 1500])))
         if kind == 3:
             accel = pt.ACCEL_BRUTE_FORCE
     w, h = int(rng.integers(1, 140)), int(rng.integers(1, 100))
