@@ -193,9 +193,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="demo1080", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=-1,
-                    help="kernel variant (-1 auto: wavefront for BVH scenes, work-stealing megakernel for scenes "
-                         "staged in LDS; 0 regeneration megakernel, 1 classic megakernel, 100 wavefront, "
-                         "500 work-stealing megakernel)")
+                    help="kernel variant (-1 auto: the path pool for scenes rendered by the linear scan, the wavefront "
+                         "launches for BVH scenes; 0 regeneration megakernel, 1 classic megakernel, "
+                         "100 wavefront, 500 work-stealing megakernel)")
     ap.add_argument("--accel", default="auto", choices=["auto", "brute"],
                     help="scenes above 192 spheres: sphere BVH (auto) or the reference's linear scan (brute)")
     ap.add_argument("--integrator", default="path", choices=["path", "nee"],
