@@ -203,7 +203,7 @@ int pt_set_kernel_variant(pt_handle h, int variant);
  *                              scan; reset by pt_init_scene)
  *   PT_TUNE_WAVEFRONT_BATCH    paths in flight of the wavefront variant in units of 2^20 (0: the
  *                              default; kept across variant changes)
- *   PT_TUNE_POOL_ITERATIONS    PT_VARIANT_AUTO, scenes that fit LDS: launches of up to this many
+ *   PT_TUNE_POOL_ITERATIONS    PT_VARIANT_AUTO, linear-scan scenes: launches of up to this many
  *                              iterations go through the path pool (default 2^30; 0: never, the
  *                              work-stealing megakernel renders; kept across variant changes)
  *   PT_TUNE_WAVEFRONT_WHOLE_PATHS  BVH scenes, how bounces map to launches: 0: one launch per
