@@ -26,6 +26,9 @@ line also carries `rccl_ranks_seen` (an all-reduce of ones) and `image_rmse_vs_s
 frame).  --workload demo4k is the 8-GPU configuration's frame (3840x2160, 128 iterations per GPU).
 
 Adds to the JSON line:
+  other_workloads  (N = 1, default workload) short runs of the other configurations with the
+                default kernels: 71 spheres at depth 16, 10 007 spheres through the BVH and by the
+                linear scan, the 4K frame
   roofline      FP32 vector-ALU roofline of the render kernel: algorithmic flops per launch
                 ((17*N_spheres + 121) per Intersect call) / HIP-event duration of the launch
   cpu_baseline  the CPU oracle (a C port of the reference's trace loop, pinned bit-exactly
@@ -149,6 +152,43 @@ def cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render=None):
     return out
 
 
+LAUNCH_NAMES = None   # filled in main(): LAUNCH_* code -> (PMC file tag, kernel name)
+
+
+def measure_other_workload(pt, torch, name, accel, steps):
+    """One more workload on this GPU, outside the headline's timed region: K steps between two
+    events on the render stream after one untimed step.  Returns its line for `other_workloads`."""
+    wl = WORKLOADS[name]
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(getattr(pt, wl["scene"]), 1)
+    cam = pt.Camera(eye, look, up, wl["width"], wl["height"], 0.0, 0.0, fov)
+    tr = pt.Pathtracer(cam, wl["depth"], seed=1)
+    try:
+        tr.Init(mats, sph, lights)
+        tr.SetAccel(pt.ACCEL_AUTO if accel == "auto" else pt.ACCEL_BRUTE_FORCE)
+        bvh = accel == "auto" and tr.AccelNodes() > 0
+        tr.SetStream(torch.cuda.current_stream().cuda_stream)
+        buf = torch.zeros(wl["width"] * wl["height"] * 3, dtype=torch.float32, device="cuda")
+        tr.RunN(buf, wl["iterations"], sync=True)       # untimed: allocations, first launch
+        tr.ResetCounters()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(steps):
+            tr.Reset()
+            tr.RunN(buf, wl["iterations"], sync=False)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / steps
+        rays = tr.RayCount() / steps
+        fpr = flops_per_ray_bvh(name) if bvh else flops_per_ray(len(sph))
+        achieved = rays * fpr / (ms * 1e-3) / 1e12 if fpr else None
+        return {"workload": wl["label"], "nearest_hit": "sphere BVH" if bvh else "linear scan", "steps": steps,
+                "ms_per_step": ms, "value": rays / (ms * 1e-3), "unit": "path-bounces/s",
+                "launch": LAUNCH_NAMES.get(tr.LastLaunch(), ("none", "none"))[1],
+                "flops_per_bounce": fpr, "roofline_frac": achieved / PEAK_FP32_VALU_TFLOPS if achieved else None}
+    finally:
+        tr.Release()
+
+
 def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N` typed without a launcher: start the N ranks as a child
     `python -m torch.distributed.run` of this same script.  This process has not touched the GPU
@@ -202,6 +242,8 @@ def main():
                     help="path: the reference's Trace (the headline metric); nee: opt-in direct-light sampling "
                          "with MIS (bounces then include the shadow rays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="N = 1, default workload: do not append the short runs of the other workloads")
     ap.add_argument("--split", default="sample", choices=["sample", "tile"],
                     help="N > 1: sample-range split (each rank its own iterations, SUM buffers) or tile split "
                          "(each rank its own 16-row bands of all iterations); one RCCL reduce(sum) either way")
@@ -376,13 +418,15 @@ def main():
     # HBM bytes per step from the committed PMC passes of this same command (rocprofv3 cannot be
     # run from inside the benchmark): profiles/pmc_traffic_<workload>_v<variant>.json
     launch = tr.LastLaunch()
-    launch_tag, launch_kernel = {
+    global LAUNCH_NAMES
+    LAUNCH_NAMES = {
         pt.LAUNCH_MEGAKERNEL: ("v0", "render_kernel"),
         pt.LAUNCH_MEGAKERNEL_STEALING: ("v500", "render_steal_kernel"),
         pt.LAUNCH_WAVEFRONT: ("v100", "wf_step_* (all launches of a step)"),
         pt.LAUNCH_WAVEFRONT_WHOLE_PATHS: ("v100whole", "wf_step_bvh_kernel<whole paths> (all launches of a step)"),
         pt.LAUNCH_PATH_POOL: ("pool", "wf_pool_kernel (+ wf_resolve_kernel; all launches of a step)"),
-    }.get(launch, ("none", "none"))
+    }
+    launch_tag, launch_kernel = LAUNCH_NAMES.get(launch, ("none", "none"))
     tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}{'_bvh' if bvh else ''}_{launch_tag}.json")
     pmc = pmc_summary(tpath) if args.integrator == "path" else {}
     traffic = pmc.get("hbm_bytes_per_step")
@@ -424,6 +468,18 @@ def main():
         }
         if multi is not None:
             out["multi_gpu"] = multi
+        if (not grouped and not args.no_other_workloads and args.workload == "demo1080" and args.variant == -1
+                and args.accel == "auto" and args.integrator == "path"):
+            # The other benchmark configurations, a few steps each with the defaults, so that one
+            # run of this file measures all of them (not part of `value`, outside its timed region).
+            others = []
+            for name, accel, k in (("mixed16", "auto", 3), ("synth10k", "auto", 2), ("synth10k", "brute", 1),
+                                   ("demo4k", "auto", 1)):
+                try:
+                    others.append(measure_other_workload(pt, torch, name, accel, k))
+                except Exception as e:   # the headline line must not depend on these
+                    others.append({"workload": WORKLOADS[name]["label"], "error": f"{type(e).__name__}: {e}"})
+            out["other_workloads"] = others
         if not grouped and not args.no_cpu_baseline and args.integrator == "path":
             def gpu_render(n):
                 tr.Reset()
