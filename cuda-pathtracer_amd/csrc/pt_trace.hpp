@@ -484,40 +484,48 @@ PT_DEV V3 camera_ray(const CameraParams &cam, uint32_t x, uint32_t y, uint32_t p
     return normalize((first - pxy * sy) + pxx * sx);
 }
 
+// Two camera rays from one Philox block: sub-samples 2*half and 2*half + 1 of a pixel-iteration,
+// the same values camera_ray() returns for them.
+PT_DEV void camera_ray_pair(const CameraParams &cam, uint32_t x, uint32_t y, uint32_t pix, uint32_t it,
+                            uint32_t half, uint32_t k0, uint32_t k1, V3 dirs[2])
+{
+    const V3 first = mk(cam.first[0], cam.first[1], cam.first[2]);
+    const V3 pxx = mk(cam.pxx[0], cam.pxx[1], cam.pxx[2]);
+    const V3 pxy = mk(cam.pxy[0], cam.pxy[1], cam.pxy[2]);
+    const float fx = (float)(int)x, fy = (float)(int)y;
+    uint32_t r[4];
+    philox4x32_10(pix, it, half, STREAM_CAMERA, k0, k1, r);
+    const float vs = half ? 0.5f : -0.5f;
+    const float sx0 = fx + u01(r[0]) * -0.5f, sy0 = fy + u01(r[1]) * vs;
+    const float sx1 = fx + u01(r[2]) * 0.5f, sy1 = fy + u01(r[3]) * vs;
+    dirs[0] = normalize((first - pxy * sy0) + pxx * sx0);
+    dirs[1] = normalize((first - pxy * sy1) + pxx * sx1);
+}
+
 // The four camera rays of one pixel-iteration at once: the same values camera_ray() returns for
 // sub = 0..3 (Philox slot 0 feeds sub-samples 0 and 1, slot 1 feeds 2 and 3), with two Philox
 // blocks instead of four.
 PT_DEV void camera_rays4(const CameraParams &cam, uint32_t x, uint32_t y, uint32_t pix, uint32_t it,
                          uint32_t k0, uint32_t k1, V3 dirs[4])
 {
-    const V3 first = mk(cam.first[0], cam.first[1], cam.first[2]);
-    const V3 pxx = mk(cam.pxx[0], cam.pxx[1], cam.pxx[2]);
-    const V3 pxy = mk(cam.pxy[0], cam.pxy[1], cam.pxy[2]);
-    const float fx = (float)(int)x, fy = (float)(int)y;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        uint32_t r[4];
-        philox4x32_10(pix, it, (uint32_t)half, STREAM_CAMERA, k0, k1, r);
-        const float vs = half ? 0.5f : -0.5f;
-        const float sx0 = fx + u01(r[0]) * -0.5f, sy0 = fy + u01(r[1]) * vs;
-        const float sx1 = fx + u01(r[2]) * 0.5f, sy1 = fy + u01(r[3]) * vs;
-        dirs[half * 2] = normalize((first - pxy * sy0) + pxx * sx0);
-        dirs[half * 2 + 1] = normalize((first - pxy * sy1) + pxx * sx1);
-    }
+    camera_ray_pair(cam, x, y, pix, it, 0u, k0, k1, dirs);
+    camera_ray_pair(cam, x, y, pix, it, 1u, k0, k1, dirs + 2);
 }
 
 // One iteration of the loop in Trace (pathtracer.cu:125-168) for a ray that hit sphere `best`
 // at distance t: emission, BSDF sample, throughput, Russian roulette, depth limit.  `s` is the
 // hit sphere's (cx, cy, cz, r*r).  Updates o, d, T, L and increments b when the path goes on;
-// returns true when the path ends.
+// returns true when the path ends -- o, d and T are then left in whatever state the exit found
+// them in (a path that has ended has no use for them), which spares the copies that keeping
+// their old values across the exits would cost.
 PT_DEV bool shade_bounce(const SceneView &sc, float4 s, int best, float t, uint32_t pix, uint32_t it,
                          uint32_t k0, uint32_t k1, int mb, V3 &o, V3 &d, V3 &T, V3 &L, int &b)
 {
     // hit point and normal: scene.h:86-87, primitive.h:74
     const float4 a = sc.aux[best];
-    const V3 P = o + d * t;
-    const V3 n = (P - mk(s.x, s.y, s.z)) * a.x;
     const V3 wo = d;
+    o = o + d * t;
+    const V3 n = (o - mk(s.x, s.y, s.z)) * a.x;
     const uint32_t mat_id = __float_as_uint(a.y);
     const int light_id = __float_as_int(a.z);
 
@@ -534,15 +542,12 @@ PT_DEV bool shade_bounce(const SceneView &sc, float4 s, int best, float t, uint3
     philox4x32_10(pix, it, (uint32_t)b, STREAM_PATH, k0, k1, r);
     const float4 m = sc.mat[mat_id];
     const int mtype = sc.mat_type[mat_id];
-    V3 wi;
     float pdf;
-    const V3 f = sample_material(mtype, mk(m.x, m.y, m.z), m.w, wo, wi, pdf, n, u01(r[0]), u01(r[1]));
+    const V3 f = sample_material(mtype, mk(m.x, m.y, m.z), m.w, wo, d, pdf, n, u01(r[0]), u01(r[1]));
     // pathtracer.cu:146-161
     if ((f.x == 0.f && f.y == 0.f && f.z == 0.f) || pdf == 0.f) return true;
     PT_LS(7);
-    T = T * vdiv(f * __builtin_fabsf(dot(wi, n)), pdf);
-    o = P;
-    d = wi;
+    T = T * vdiv(f * __builtin_fabsf(dot(d, n)), pdf);
     bool end = false;
     if (b > 3) {
         PT_LS(8);
