@@ -376,6 +376,9 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
         mat[i] = make_float4(materials[i].color[0], materials[i].color[1], materials[i].color[2],
                              materials[i].coef);
         mtype[i] = materials[i].type;
+        // A material of unknown type scatters nothing (SampleMaterial returns a black f,
+        // scene.h:179,220); the kernels get that as colour 0 (sample_material multiplies it by 0).
+        if (mtype[i] < 0 || mtype[i] > 2) mat[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     std::vector<float4> light_geom(n_lights ? n_lights : 1);
     for (uint32_t i = 0; i < n_lights; ++i) {

@@ -323,19 +323,16 @@ PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &
     if (do_reflect) { PT_LS(15); wi = reflect(wo, nnor); }
     else            { PT_LS(16); wi = normalize(vec); }
 
-    V3 f = mk(0.f, 0.f, 0.f);
+    // f and pdf: scene.h:185-186 with Material::F (material.h:37-43: 0 + color/pi), 191-192, 216-217.
+    // x * 1.f == x; an unknown material type gets f = color * 0, black, which ends the path
+    // (pathtracer.cu:146) before wi or pdf are looked at.
+    V3 f;
     if (is_d) {
         pdf = dot(wo, wi) < 0.f ? __builtin_fabsf(dot(wi, n)) * PT_INV_PI : 0.f;
-        f = f + color * PT_INV_PI;
-    } else if (is_s) {
-        pdf = 1.f;
-        f = color * coef;
-    } else if (is_g) {
-        pdf = 1.f;
-        f = color;
+        f = mk(0.f, 0.f, 0.f) + color * PT_INV_PI;
     } else {
-        wi = mk(0.f, 0.f, 0.f);
-        pdf = 0.f;
+        pdf = 1.f;
+        f = color * (is_s ? coef : (is_g ? 1.f : 0.f));
     }
     return f;
 }

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontP
                 const uint32_t j = base + (TILED ? lane : 2u * lane);
                 const uint64_t i = ((uint64_t)(j >> 8) * kWfSubQueues + q) * kBlockThreads + (j & 255u);
                 const bool valid = j < n_items && i < n_paths;   // the number of paths is a multiple of 4
-                PoolEntry e0 = {0.f, 0.f, 1.f, 0u, 0u}, e1 = e0;
+                PoolEntry e0, e1;   // written to the ring by valid lanes only
                 if (valid) {
                     const uint64_t ip = i >> 2;
                     uint32_t local, x, y;

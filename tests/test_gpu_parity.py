@@ -160,7 +160,8 @@ def test_scene_with_more_materials_than_lds_holds(pt, O, torch_cuda):
 def test_empty_and_degenerate_scenes(pt, O, torch_cuda):
     """Edge cases against the oracle, every kernel variant: no spheres at all (every path is one
     Intersect call that misses), spheres but no light, a 1x1 image, depth 0, a sphere of radius 0, a
-    sphere with a NaN coordinate and one with an infinite radius."""
+    sphere with a NaN coordinate and one with an infinite radius, materials of unknown type (they
+    scatter nothing: scene.h:179,220) with finite and infinite colours."""
     eye, look, up = [0, 45, 79.5], [0, 35, 0], [0, 1, 0]
     demo = pt.build_scene(pt.SCENE_DEMO, 1)
     mats, sph, lights = demo[0], demo[1], demo[2]
@@ -171,9 +172,13 @@ def test_empty_and_degenerate_scenes(pt, O, torch_cuda):
     weird["pos"][7, 1] = np.nan
     weird = np.concatenate([weird, weird[:1]])
     weird["radius"][-1] = np.inf
+    odd = mats.copy()
+    odd["type"][int(sph["material_id"][0])] = 7
+    odd["type"][int(sph["material_id"][7])] = -1
+    odd["color"][int(sph["material_id"][7])] = [np.inf, 0.5, np.nan]
     cases = [  # materials, spheres, lights, (w, h), depth, iterations
         (none_m, none_s, none_l, (20, 12), 8, 5), (mats, dark, none_l, (24, 24), 8, 4), (mats, sph, lights, (1, 1), 8, 16),
-        (mats, sph, lights, (33, 18), 0, 6), (mats, weird, lights, (40, 30), 8, 6),
+        (mats, sph, lights, (33, 18), 0, 6), (mats, weird, lights, (40, 30), 8, 6), (odd, sph, lights, (40, 30), 8, 6),
     ]
     for m, s, l, (w, h), depth, n in cases:
         cam = pt.Camera(eye, look, up, w, h, 0, 0, 60.0)
