@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --no-cpu-baseline $*"
+BENCH="python3 $REPO/bench.py --no-cpu-baseline --no-other-workloads $*"
 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- $BENCH > "$OUT/kt.log" 2>&1 || { echo "kernel-trace failed"; tail -5 "$OUT/kt.log"; exit 1; }
 
