@@ -93,7 +93,8 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
 
 /* Pathtracer::Init, pathtracer.cu:172-220: uploads the scene (repacked to SoA).  The arrays
  * may be freed after the call.  n_materials is honoured (the reference copies pv.size()
- * materials, pathtracer.cu:194). */
+ * materials, pathtracer.cu:194).  A material whose type is none of the three scatters nothing:
+ * SampleMaterial leaves f black for it (scene.h:179,220) and the path ends there. */
 int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_materials,
                   const pt_sphere *spheres, uint32_t n_spheres,
                   const pt_light *lights, uint32_t n_lights);
