@@ -256,13 +256,16 @@ PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &
     // ---- diffuse: ConcentricSampleDisk up to its division, montecarlo.h:76-114
     const float sx = 2.f * su - 1.f;
     const float sy = 2.f * sv - 1.f;
-    const bool upper = sx >= -sy;            // regions 1, 2
-    const bool r1 = upper && sx > sy;
-    const bool r2 = upper && !r1;
-    const bool r3 = !upper && sx <= sy;
-    const float num = (r1 || r3) ? sy : sx;
-    const float r = r1 ? sx : (r2 ? sy : (r3 ? -sx : -sy));
-    const float off = r1 ? (sy > 0.f ? 0.f : 8.f) : (r2 ? 2.f : (r3 ? 4.f : 6.f));
+    // Regions 1..4 of montecarlo.h:91-113: 1 = upper && gt, 2 = upper && !gt, 3 = !upper && !gt,
+    // 4 = !upper && gt (sx and sy are finite, so `sx <= sy` is !(sx > sy)).  The radius is sx, sy,
+    // -sx, -sy there: the component of the larger magnitude, which is positive in regions 1, 2
+    // and negative in 3, 4 -- its absolute value in all four.
+    const bool upper = sx >= -sy;
+    const bool gt = sx > sy;
+    const bool xdom = upper == gt;           // regions 1, 3
+    const float num = xdom ? sy : sx;
+    const float r = __builtin_fabsf(xdom ? sx : sy);
+    const float off = xdom ? (upper ? (sy > 0.f ? 0.f : 8.f) : 4.f) : (upper ? 2.f : 6.f);
 
     // ---- division 1: diffuse num/r | glass from outside 1/coef
     const float q = pt_div(is_g ? 1.f : num, is_g ? coef : r);
@@ -282,7 +285,7 @@ PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &
     } else {
         PT_LS(12);
         // montecarlo.h:115-117, 129-130
-        float theta = (r2 || r3) ? off - q : off + q;
+        float theta = gt ? off + q : off - q;   // minus in regions 2, 3
         theta *= PT_M_PI / 4.f;
         float s, c;
         pt_sincosf(theta, s, c);
