@@ -86,6 +86,7 @@ ABI = [
     ("pt_read_image", _i32, [_vp, _vp, _vp]),
     ("pt_debug_trace", _i32, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _pu64]),
     ("pt_selftest_eval", _i32, [_vp, _i32, _vp, _vp, _vp, _u64]),
+    ("pt_selftest_sample_material", _i32, [_vp, _vp, _vp, _vp, _u64]),
     ("pt_selftest_exhaustive", _i32, [_vp, _i32, _pu64]),
     ("pt_camera_state_init", _i32, [_vp, _vp, _vp, _vp, _u32, _u32, ctypes.c_float]),
     ("pt_camera_translate", _i32, [_vp, _vp]),
@@ -430,6 +431,14 @@ class Pathtracer:
         out = np.empty_like(a)
         self._check(self._lib.pt_selftest_eval(self._h, op, _ptr(a), None if bb is None else _ptr(bb),
                                                _ptr(out), a.size))
+        return out
+
+    def SelftestSampleMaterial(self, material: np.ndarray, rows: np.ndarray) -> np.ndarray:
+        """rows [n, 8] = wo.xyz, n.xyz, u, v -> [n, 8] = f.rgb, wi.xyz, pdf, 0 (one MATERIAL_DTYPE record)."""
+        m = np.ascontiguousarray(material, MATERIAL_DTYPE).reshape(-1)[:1]
+        x = np.ascontiguousarray(rows, np.float32).reshape(-1, 8)
+        out = np.empty_like(x)
+        self._check(self._lib.pt_selftest_sample_material(self._h, _ptr(m), _ptr(x), _ptr(out), len(x)))
         return out
 
     def SelftestExhaustive(self, op: int) -> int:

@@ -1418,6 +1418,31 @@ done:
     return rc;
 }
 
+int pt_selftest_sample_material(pt_handle h, const pt_material *material, const float *in, float *out, uint64_t n)
+{
+    if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
+    if (!material || !in || !out) return fail(h, PT_ERR_INVALID, "pt_selftest_sample_material: bad arguments");
+    if (n == 0) return PT_OK;
+    // the table entry pt_init_scene would upload for this material
+    float4 cc = make_float4(material->color[0], material->color[1], material->color[2], material->coef);
+    if (material->type < 0 || material->type > 2) cc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float *din = nullptr, *dout = nullptr;
+    int rc = PT_OK;
+    hipError_t e = hipSuccess;
+    ST_HIP(hipMalloc((void **)&din, n * 8 * sizeof(float)));
+    ST_HIP(hipMalloc((void **)&dout, n * 8 * sizeof(float)));
+    ST_HIP(hipMemcpyAsync(din, in, n * 8 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    ST_HIP(launch_selftest_material(material->type, cc, din, dout, n, h->stream));
+    ST_HIP(hipMemcpyAsync(out, dout, n * 8 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    ST_HIP(hipStreamSynchronize(h->stream));
+done:
+    if (rc != PT_OK) (void)hipStreamSynchronize(h->stream);
+    if (din) (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
 int pt_selftest_exhaustive(pt_handle h, int op, uint64_t *mismatches)
 {
     if (!h || !mismatches) return PT_ERR_INVALID;

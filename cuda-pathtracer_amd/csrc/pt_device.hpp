@@ -287,11 +287,13 @@ PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &
         // montecarlo.h:115-117, 129-130
         float theta = gt ? off + q : off - q;   // minus in regions 2, 3
         theta *= PT_M_PI / 4.f;
+        // montecarlo.h:85-89: (0, 0) maps to (0, 0).  There r == 0 and q is 0/0; with theta = 0 the
+        // sine and cosine are exactly 0 and 1, and r * c, r * s are the +0 the reference returns.
+        if (r == 0.f) theta = 0.f;
         float s, c;
         pt_sincosf(theta, s, c);
-        const bool origin = sx == 0.f && sy == 0.f;   // montecarlo.h:85-89
-        ret.x = origin ? 0.f : r * c;
-        ret.y = origin ? 0.f : r * s;
+        ret.x = r * c;
+        ret.y = r * s;
         const float e = 1.f - ret.x * ret.x - ret.y * ret.y;
         root_arg = 0.f > e ? 0.f : e;
     }

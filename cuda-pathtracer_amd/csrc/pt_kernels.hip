@@ -571,6 +571,20 @@ __global__ void selftest_eval_kernel(int op, const float *a, const float *b, flo
     if (i < n) out[i] = selftest_op(op, a[i], b ? b[i] : 0.f);
 }
 
+// sample_material row by row: in [n][8] = wo.xyz, n.xyz, su, sv; out [n][8] = f.rgb, wi.xyz, pdf, 0
+__global__ void selftest_material_kernel(int type, float4 color_coef, const float *in, float *out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *x = in + 8 * i;
+    float *y = out + 8 * i;
+    V3 wi = mk(0.f, 0.f, 0.f);
+    float pdf = 0.f;
+    const V3 f = sample_material(type, mk(color_coef.x, color_coef.y, color_coef.z), color_coef.w, mk(x[0], x[1], x[2]),
+                                 wi, pdf, mk(x[3], x[4], x[5]), x[6], x[7]);
+    y[0] = f.x; y[1] = f.y; y[2] = f.z; y[3] = wi.x; y[4] = wi.y; y[5] = wi.z; y[6] = pdf; y[7] = 0.f;
+}
+
 // Compares the short sequences with the compiler's generic IEEE expansions: every one of the
 // 2^32 bit patterns for sqrt and 1/x, 2^32 Philox-random operand pairs for a/b.
 __global__ void selftest_exhaustive_kernel(int op, unsigned long long *mismatches)
@@ -606,6 +620,12 @@ hipError_t launch_selftest_eval(int op, const float *a, const float *b, float *o
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(selftest_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, op, a, b, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_material(int type, float4 color_coef, const float *in, float *out, uint64_t n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(selftest_material_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, type, color_coef, in, out, n);
     return hipGetLastError();
 }
 

@@ -195,6 +195,7 @@ hipError_t launch_wavefront_resolve(const WavefrontParams &p, hipStream_t stream
 // trace loop uses; exhaustive comparison of the short sqrt / reciprocal / division sequences
 // against the compiler's IEEE expansions.
 hipError_t launch_selftest_eval(int op, const float *a, const float *b, float *out, uint64_t n, hipStream_t stream);
+hipError_t launch_selftest_material(int type, float4 color_coef, const float *in, float *out, uint64_t n, hipStream_t stream);
 hipError_t launch_selftest_exhaustive(int op, unsigned long long *mismatches, hipStream_t stream);
 
 } // namespace ptmi

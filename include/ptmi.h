@@ -330,6 +330,11 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
  *   expansion over all 2^32 float bit patterns (op 0, 1) or 2^32 random operand pairs (op 2). */
 int pt_selftest_eval(pt_handle h, int op, const float *a, const float *b, float *out, uint64_t n);
 int pt_selftest_exhaustive(pt_handle h, int op, uint64_t *mismatches);
+/* SampleMaterial (scene.h:177-221) as the kernels evaluate it, row by row on the device: in
+ * [n][8] = wo.xyz, n.xyz, u, v; out [n][8] = f.rgb, wi.xyz, pdf, 0.  Host pointers.  For a material
+ * of unknown type only f (black) is defined. */
+int pt_selftest_sample_material(pt_handle h, const pt_material *material, const float *in, float *out,
+                                uint64_t n);
 
 /* ---- host-side scene helpers (plain host code, no device needed) ------------------------- */
 

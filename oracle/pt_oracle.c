@@ -452,6 +452,22 @@ static void *worker(void *arg)
     return NULL;
 }
 
+/* Test hook: SampleMaterial (scene.h:177-221) row by row.  in: [n][8] = wo.xyz, n.xyz, su, sv;
+ * out: [n][8] = f.rgb, wi.xyz, pdf, 0. */
+int ptor_sample_material_eval(const ptor_material *mat, const float *in, float *out, uint32_t n)
+{
+    if (!mat || !in || !out) return -1;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *x = in + 8 * (size_t)i;
+        float *y = out + 8 * (size_t)i;
+        v3 wi = v3_make(0.f, 0.f, 0.f);
+        float pdf = 0.f;
+        const v3 f = sample_material(mat, v3_make(x[0], x[1], x[2]), &wi, &pdf, v3_make(x[3], x[4], x[5]), x[6], x[7]);
+        y[0] = f.x; y[1] = f.y; y[2] = f.z; y[3] = wi.x; y[4] = wi.y; y[5] = wi.z; y[6] = pdf; y[7] = 0.f;
+    }
+    return 0;
+}
+
 int ptor_render(const ptor_camera *cam,
                 const ptor_material *mats, uint32_t n_mats,
                 const ptor_sphere *prims, uint32_t n_prims,

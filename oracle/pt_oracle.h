@@ -145,6 +145,10 @@ enum {
     PTOR_NEE_SPHERE_SAMPLE_AREA, PTOR_NEE_SPHERE_SAMPLE_FROM, PTOR_NEE_LIGHT_PDF, PTOR_NEE_INTERSECT_P,
     PTOR_NEE_SAMPLE_LIGHT
 };
+/* SampleMaterial (scene.h:177-221) for n rows: in [n][8] = wo.xyz, n.xyz, su, sv; out [n][8] =
+ * f.rgb, wi.xyz, pdf, 0. */
+int ptor_sample_material_eval(const ptor_material *mat, const float *in, float *out, uint32_t n);
+
 int ptor_nee_eval(int op, int as_written,
                   const ptor_material *mats, uint32_t n_mats, const ptor_sphere *prims, uint32_t n_prims,
                   const ptor_light *lights, uint32_t n_lights, const float *in, float *out, uint32_t count);

@@ -76,3 +76,45 @@ def test_sincos_matches_oracle_bitwise(tracer, O):
         lib.ptor_sincos(float(x), ctypes.byref(s), ctypes.byref(c))
         s_ref[i], c_ref[i] = s.value, c.value
     assert same_bits(s_dev, s_ref) and same_bits(c_dev, c_ref)
+
+
+def _material_rows(rng, n):
+    """wo, n, u, v: unit normals, directions towards and away from the surface, and samples on the
+    lattice u01() produces, with the disk mapping's region boundaries and its origin over-represented."""
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    wo = rng.normal(size=(n, 3)); wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    grazing = rng.random(n) < 0.1     # nearly tangent directions: total internal reflection, tiny cosines
+    wo[grazing] -= (np.sum(wo[grazing] * nrm[grazing], axis=1, keepdims=True) * nrm[grazing]) * 0.999
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    u = (rng.integers(0, 2**24, n) * 2.0**-24)
+    v = (rng.integers(0, 2**24, n) * 2.0**-24)
+    k = n // 8
+    v[:k] = u[:k]                      # sx == sy
+    v[k:2 * k] = 1.0 - u[k:2 * k]      # sx == -sy
+    u[2 * k:2 * k + 64] = 0.5          # sx == 0 ...
+    v[2 * k + 32:2 * k + 96] = 0.5     # ... sy == 0, both for 32 rows: the origin
+    u[2 * k + 96:2 * k + 128] = 0.0
+    v[2 * k + 112:2 * k + 144] = 0.0
+    rows = np.zeros((n, 8), np.float32)
+    rows[:, 0:3], rows[:, 3:6], rows[:, 6], rows[:, 7] = wo, nrm, u, v
+    return rows
+
+
+@pytest.mark.parametrize("mtype,coef", [(0, 0.0), (1, 0.9), (2, 1.5), (2, 2.4), (7, 0.3)])
+def test_sample_material_matches_oracle_bitwise(pt, tracer, O, mtype, coef):
+    """SampleMaterial as the kernels evaluate it (the staged BSDF of pt_device.hpp) against the
+    oracle's statement-by-statement version (scene.h:177-221): f, wi and pdf bit for bit."""
+    lib = O.load_oracle()
+    rows = _material_rows(np.random.default_rng(11 + mtype), 200000)
+    mat = np.zeros(1, pt.MATERIAL_DTYPE)
+    mat["color"], mat["coef"], mat["type"] = [[0.75, 0.25, 0.9]], coef, mtype
+    dev = tracer.SelftestSampleMaterial(mat, rows)
+    ref = np.zeros_like(rows)
+    lib.ptor_sample_material_eval.restype = ctypes.c_int32
+    lib.ptor_sample_material_eval.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint32]
+    omat = np.ascontiguousarray(mat, O.MATERIAL_DTYPE)
+    assert lib.ptor_sample_material_eval(omat.ctypes.data, rows.ctypes.data, ref.ctypes.data, len(rows)) == 0
+    cols = slice(0, 3) if mtype > 2 else slice(0, 7)   # unknown type: only f (black) is defined
+    bad = np.argwhere(~((dev[:, cols].view(np.uint32) == ref[:, cols].view(np.uint32))
+                        | (np.isnan(dev[:, cols]) & np.isnan(ref[:, cols]))))
+    assert bad.size == 0, (bad[:4], rows[bad[0, 0]], dev[bad[0, 0]], ref[bad[0, 0]])
