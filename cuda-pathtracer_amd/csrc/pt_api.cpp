@@ -334,6 +334,23 @@ int pt_destroy(pt_handle h)
     return PT_OK;
 }
 
+// Device table entry of a material: (f, coef) with f the value SampleMaterial returns for it, which
+// depends on the material alone -- diffuse: Material::F, 0 + color * INV_PI (material.h:37-43,
+// scene.h:186); specular: coef * color (scene.h:191); refractive: color (scene.h:216); any other
+// type: black (scene.h:179,220).  Same fp32 operations as the reference performs per bounce
+// (this file is compiled without contraction).
+static float4 material_table_entry(const pt_material &m)
+{
+    const float inv_pi = 0.31830988618379067154f;
+    float f[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 3; ++k) {
+        if (m.type == 0) f[k] = 0.f + m.color[k] * inv_pi;
+        else if (m.type == 1) f[k] = m.color[k] * m.coef;
+        else if (m.type == 2) f[k] = m.color[k];
+    }
+    return make_float4(f[0], f[1], f[2], m.coef);
+}
+
 int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_materials,
                   const pt_sphere *spheres, uint32_t n_spheres,
                   const pt_light *lights, uint32_t n_lights)
@@ -373,12 +390,8 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
     std::vector<float4> mat(n_materials ? n_materials : 1), light(n_lights ? n_lights : 1);
     std::vector<int> mtype(n_materials ? n_materials : 1);
     for (uint32_t i = 0; i < n_materials; ++i) {
-        mat[i] = make_float4(materials[i].color[0], materials[i].color[1], materials[i].color[2],
-                             materials[i].coef);
+        mat[i] = material_table_entry(materials[i]);
         mtype[i] = materials[i].type;
-        // A material of unknown type scatters nothing (SampleMaterial returns a black f,
-        // scene.h:179,220); the kernels get that as colour 0 (sample_material multiplies it by 0).
-        if (mtype[i] < 0 || mtype[i] > 2) mat[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     std::vector<float4> light_geom(n_lights ? n_lights : 1);
     for (uint32_t i = 0; i < n_lights; ++i) {
@@ -1424,9 +1437,7 @@ int pt_selftest_sample_material(pt_handle h, const pt_material *material, const 
     DeviceGuard on_device(h->device);
     if (!material || !in || !out) return fail(h, PT_ERR_INVALID, "pt_selftest_sample_material: bad arguments");
     if (n == 0) return PT_OK;
-    // the table entry pt_init_scene would upload for this material
-    float4 cc = make_float4(material->color[0], material->color[1], material->color[2], material->coef);
-    if (material->type < 0 || material->type > 2) cc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 cc = material_table_entry(*material);
     float *din = nullptr, *dout = nullptr;
     int rc = PT_OK;
     hipError_t e = hipSuccess;

@@ -243,7 +243,7 @@ PT_DEV float reflectance(V3 inc, V3 nor, float n1, float n2)
 //     (rOrth, rPar) = (X, Y) from outside and (Y, X) from inside, and X*X + Y*Y == Y*Y + X*X;
 //   - Refract's cost = wo.n is -cosI, so its cos2t = 1 - eta*eta*(1 - cost*cost) is the very
 //     value 1 - sinT2 whose root reflectance() already took: sqrt(cos2t) == cosT.
-PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &pdf, V3 n,
+PT_DEV V3 sample_material(int type, V3 f_mat, float coef, V3 wo, V3 &wi, float &pdf, V3 n,
                           float su, float sv)
 {
     const bool is_d = type == 0, is_s = type == 1, is_g = type == 2;
@@ -328,18 +328,12 @@ PT_DEV V3 sample_material(int type, V3 color, float coef, V3 wo, V3 &wi, float &
     if (do_reflect) { PT_LS(15); wi = reflect(wo, nnor); }
     else            { PT_LS(16); wi = normalize(vec); }
 
-    // f and pdf: scene.h:185-186 with Material::F (material.h:37-43: 0 + color/pi), 191-192, 216-217.
-    // x * 1.f == x; an unknown material type gets f = color * 0, black, which ends the path
-    // (pathtracer.cu:146) before wi or pdf are looked at.
-    V3 f;
-    if (is_d) {
-        pdf = dot(wo, wi) < 0.f ? __builtin_fabsf(dot(wi, n)) * PT_INV_PI : 0.f;
-        f = mk(0.f, 0.f, 0.f) + color * PT_INV_PI;
-    } else {
-        pdf = 1.f;
-        f = color * (is_s ? coef : (is_g ? 1.f : 0.f));
-    }
-    return f;
+    // pdf: scene.h:185, 190, 217.  f (scene.h:186 with Material::F, material.h:37-43: 0 + color/pi;
+    // 191: coef * color; 216: color) depends on the material alone: the host computes it with the
+    // same fp32 operations when the scene is uploaded and f_mat is that value (black for an unknown
+    // material type, which ends the path, pathtracer.cu:146, before wi or pdf are looked at).
+    pdf = is_d ? (dot(wo, wi) < 0.f ? __builtin_fabsf(dot(wi, n)) * PT_INV_PI : 0.f) : 1.f;
+    return f_mat;
 }
 
 // ---- nearest hit --------------------------------------------------------------------------

@@ -244,7 +244,7 @@ PT_DEV bool shade_bounce_nee(const SceneParams &sp, const SceneView &sc, float4 
             st.sh_tmax = PT_INF;
         }
         if (pdf_l > 0.f && !(li.x == 0.f && li.y == 0.f && li.z == 0.f)) {
-            const V3 fl = mk(m.x, m.y, m.z) * PT_INV_PI;                      // Material::F, material.h:37-43
+            const V3 fl = mk(m.x, m.y, m.z);   // Material::F, material.h:37-43: the table holds 0 + color/pi for diffuse materials
             const float bp = -dot(wo, wl) > 0.f ? dot(wl, n) * PT_INV_PI : 0.f;   // Pdf(mat, ...), scene.h:136-144
             if (!(fl.x == 0.f && fl.y == 0.f && fl.z == 0.f) && bp > 0.f) {
                 const float pl = pdf_l * inv_nl;
