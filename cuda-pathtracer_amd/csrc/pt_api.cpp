@@ -33,7 +33,7 @@ struct pt_context {
     int device;
     // scene (device)
     float4 *d_sph, *d_aux, *d_mat, *d_light, *d_light_geom;
-    int *d_mat_type;
+    int2 *d_mat_type;   // (type, bits of 1.f / coef)
     int integrator;       // PT_INTEGRATOR_*
     uint32_t n_prims, n_mats, n_lights;
     bool scene_ready;
@@ -351,6 +351,16 @@ static float4 material_table_entry(const pt_material &m)
     return make_float4(f[0], f[1], f[2], m.coef);
 }
 
+// Second table entry of a material: its type and n1/n2 of a ray that enters a refractive material,
+// 1.f / coef (scene.h:199-201, 213), which depends on the material alone.
+static int2 material_type_entry(const pt_material &m)
+{
+    const float inv_coef = 1.f / m.coef;
+    int bits;
+    memcpy(&bits, &inv_coef, 4);
+    return make_int2(m.type, bits);
+}
+
 int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_materials,
                   const pt_sphere *spheres, uint32_t n_spheres,
                   const pt_light *lights, uint32_t n_lights)
@@ -388,10 +398,10 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
         aux[i] = make_float4(1.f / s.radius, mbits, lbits, s.radius);
     }
     std::vector<float4> mat(n_materials ? n_materials : 1), light(n_lights ? n_lights : 1);
-    std::vector<int> mtype(n_materials ? n_materials : 1);
+    std::vector<int2> mtype(n_materials ? n_materials : 1);
     for (uint32_t i = 0; i < n_materials; ++i) {
         mat[i] = material_table_entry(materials[i]);
-        mtype[i] = materials[i].type;
+        mtype[i] = material_type_entry(materials[i]);
     }
     std::vector<float4> light_geom(n_lights ? n_lights : 1);
     for (uint32_t i = 0; i < n_lights; ++i) {
@@ -1444,7 +1454,7 @@ int pt_selftest_sample_material(pt_handle h, const pt_material *material, const 
     ST_HIP(hipMalloc((void **)&din, n * 8 * sizeof(float)));
     ST_HIP(hipMalloc((void **)&dout, n * 8 * sizeof(float)));
     ST_HIP(hipMemcpyAsync(din, in, n * 8 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    ST_HIP(launch_selftest_material(material->type, cc, din, dout, n, h->stream));
+    ST_HIP(launch_selftest_material(material->type, cc, 1.f / material->coef, din, dout, n, h->stream));
     ST_HIP(hipMemcpyAsync(out, dout, n * 8 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     ST_HIP(hipStreamSynchronize(h->stream));
 done:

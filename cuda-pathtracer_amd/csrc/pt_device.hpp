@@ -91,6 +91,16 @@ PT_DEV float pt_div(float a, float b)
     return a / b;
 }
 
+// pt_div for operands known to lie in its fast range: 2^-30 <= |b| < 2^30 and a == 0 or in the
+// same range (no test, no fallback; b == 0 gives NaN).
+PT_DEV float pt_div_in_range(float a, float b)
+{
+    const float r = rcp_newton(b);
+    const float q = a * r;
+    const float e = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e, r, q);
+}
+
 struct V3 { float x, y, z; };
 
 // geometry.h:91-133: Vec / Point / Color arithmetic; `a / s` is `a * (1.f / s)`.
@@ -237,13 +247,14 @@ PT_DEV float reflectance(V3 inc, V3 nor, float n1, float n2)
 // lanes, and only what is left (two Fresnel quotients) runs for the glass lanes alone.  Every
 // value is produced by the same IEEE operations on the same operands as in the reference's
 // order; the identities used are exact in fp32:
-//   - n1/n2 is 1/coef from outside and coef/1 == coef from inside (scene.h:199-209);
+//   - n1/n2 is 1/coef from outside and coef/1 == coef from inside (scene.h:199-209); 1/coef depends
+//     on the material alone and comes from the material table (inv_coef, computed by the host);
 //   - x*1.f == x, so with n1 or n2 equal to 1 the two Fresnel quotients (globals.h:122-123) are
 //     X = (cosI - coef*cosT)/(cosI + coef*cosT) and Y = (coef*cosI - cosT)/(coef*cosI + cosT),
 //     (rOrth, rPar) = (X, Y) from outside and (Y, X) from inside, and X*X + Y*Y == Y*Y + X*X;
 //   - Refract's cost = wo.n is -cosI, so its cos2t = 1 - eta*eta*(1 - cost*cost) is the very
 //     value 1 - sinT2 whose root reflectance() already took: sqrt(cos2t) == cosT.
-PT_DEV V3 sample_material(int type, V3 f_mat, float coef, V3 wo, V3 &wi, float &pdf, V3 n,
+PT_DEV V3 sample_material(int type, V3 f_mat, float coef, float inv_coef, V3 wo, V3 &wi, float &pdf, V3 n,
                           float su, float sv)
 {
     const bool is_d = type == 0, is_s = type == 1, is_g = type == 2;
@@ -267,8 +278,9 @@ PT_DEV V3 sample_material(int type, V3 f_mat, float coef, V3 wo, V3 &wi, float &
     const float r = __builtin_fabsf(xdom ? sx : sy);
     const float off = xdom ? (upper ? (sy > 0.f ? 0.f : 8.f) : 4.f) : (upper ? 2.f : 6.f);
 
-    // ---- division 1: diffuse num/r | glass from outside 1/coef
-    const float q = pt_div(is_g ? 1.f : num, is_g ? coef : r);
+    // ---- division 1 (diffuse): num/r.  Both are multiples of 2^-23 with |num| <= r <= 1; r == 0 only
+    // at the disk's origin, where the quotient is not used.
+    const float q = pt_div_in_range(num, r);
 
     float root_arg, cosI = 0.f, eta = 1.f;
     bool tir = false;
@@ -277,7 +289,7 @@ PT_DEV V3 sample_material(int type, V3 f_mat, float coef, V3 wo, V3 &wi, float &
     if (is_g) {
         PT_LS(11);
         // reflectance(), globals.h:117-121
-        eta = outside ? q : coef;
+        eta = outside ? inv_coef : coef;
         cosI = -(dot(nnor, wo));
         const float sinT2 = eta * eta * (1.0f - cosI * cosI);
         tir = sinT2 > 1.0f;

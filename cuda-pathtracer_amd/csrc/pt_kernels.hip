@@ -572,7 +572,7 @@ __global__ void selftest_eval_kernel(int op, const float *a, const float *b, flo
 }
 
 // sample_material row by row: in [n][8] = wo.xyz, n.xyz, su, sv; out [n][8] = f.rgb, wi.xyz, pdf, 0
-__global__ void selftest_material_kernel(int type, float4 color_coef, const float *in, float *out, uint64_t n)
+__global__ void selftest_material_kernel(int type, float4 color_coef, float inv_coef, const float *in, float *out, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -580,7 +580,7 @@ __global__ void selftest_material_kernel(int type, float4 color_coef, const floa
     float *y = out + 8 * i;
     V3 wi = mk(0.f, 0.f, 0.f);
     float pdf = 0.f;
-    const V3 f = sample_material(type, mk(color_coef.x, color_coef.y, color_coef.z), color_coef.w, mk(x[0], x[1], x[2]),
+    const V3 f = sample_material(type, mk(color_coef.x, color_coef.y, color_coef.z), color_coef.w, inv_coef, mk(x[0], x[1], x[2]),
                                  wi, pdf, mk(x[3], x[4], x[5]), x[6], x[7]);
     y[0] = f.x; y[1] = f.y; y[2] = f.z; y[3] = wi.x; y[4] = wi.y; y[5] = wi.z; y[6] = pdf; y[7] = 0.f;
 }
@@ -623,9 +623,9 @@ hipError_t launch_selftest_eval(int op, const float *a, const float *b, float *o
     return hipGetLastError();
 }
 
-hipError_t launch_selftest_material(int type, float4 color_coef, const float *in, float *out, uint64_t n, hipStream_t stream)
+hipError_t launch_selftest_material(int type, float4 color_coef, float inv_coef, const float *in, float *out, uint64_t n, hipStream_t stream)
 {
-    hipLaunchKernelGGL(selftest_material_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, type, color_coef, in, out, n);
+    hipLaunchKernelGGL(selftest_material_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, type, color_coef, inv_coef, in, out, n);
     return hipGetLastError();
 }
 
@@ -688,7 +688,7 @@ hipError_t static_steal_scratch(int device, StealScratch *out)
 size_t scene_lds_bytes(const SceneParams &s, bool tiled)
 {
     if (tiled) return (size_t)kTileSpheres * sizeof(float4);
-    const size_t n = (size_t)s.n_prims * 2 * sizeof(float4) + (size_t)s.n_mats * (sizeof(float4) + sizeof(int)) +
+    const size_t n = (size_t)s.n_prims * 2 * sizeof(float4) + (size_t)s.n_mats * (sizeof(float4) + sizeof(int2)) +
                      (size_t)s.n_lights * sizeof(float4);
     return (n + 15) & ~(size_t)15;
 }

@@ -83,7 +83,7 @@ struct SceneParams {
     const float4 *sph;   // (cx, cy, cz, radius*radius)
     const float4 *aux;   // (1/radius, materialId bits, lightId bits, radius)
     const float4 *mat;   // (r, g, b, coef)
-    const int *mat_type; // material.h:25
+    const int2 *mat_type; // (material.h:25, bits of 1.f / coef)
     const float4 *light; // (r, g, b, -) intensity
     const float4 *light_geom; // point light: (x, y, z, bits 0); area light: (bits sphere index, -, -, bits 1)
     uint32_t n_prims, n_mats, n_lights;
@@ -195,7 +195,7 @@ hipError_t launch_wavefront_resolve(const WavefrontParams &p, hipStream_t stream
 // trace loop uses; exhaustive comparison of the short sqrt / reciprocal / division sequences
 // against the compiler's IEEE expansions.
 hipError_t launch_selftest_eval(int op, const float *a, const float *b, float *out, uint64_t n, hipStream_t stream);
-hipError_t launch_selftest_material(int type, float4 color_coef, const float *in, float *out, uint64_t n, hipStream_t stream);
+hipError_t launch_selftest_material(int type, float4 color_coef, float inv_coef, const float *in, float *out, uint64_t n, hipStream_t stream);
 hipError_t launch_selftest_exhaustive(int op, unsigned long long *mismatches, hipStream_t stream);
 
 } // namespace ptmi

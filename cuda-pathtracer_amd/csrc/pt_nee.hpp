@@ -201,7 +201,8 @@ PT_DEV bool shade_bounce_nee(const SceneParams &sp, const SceneView &sc, float4 
     uint32_t r[4];
     philox4x32_10(pix, it, (uint32_t)b, STREAM_PATH, k0, k1, r);
     const float4 m = sc.mat[mat_id];
-    const int mtype = sc.mat_type[mat_id];
+    const int2 mt = sc.mat_type[mat_id];
+    const int mtype = mt.x;
 
     st.shadow = false;
     if (mtype == 0 && sp.n_lights > 0) {
@@ -259,7 +260,7 @@ PT_DEV bool shade_bounce_nee(const SceneParams &sp, const SceneView &sc, float4 
 
     V3 wi;
     float pdf;
-    const V3 f = sample_material(mtype, mk(m.x, m.y, m.z), m.w, wo, wi, pdf, n, u01(r[0]), u01(r[1]));
+    const V3 f = sample_material(mtype, mk(m.x, m.y, m.z), m.w, __int_as_float(mt.y), wo, wi, pdf, n, u01(r[0]), u01(r[1]));
     o = P;   // the shadow ray starts here as well
     if ((f.x == 0.f && f.y == 0.f && f.z == 0.f) || pdf == 0.f) return true;
     st.specular_bounce = mtype != 0;

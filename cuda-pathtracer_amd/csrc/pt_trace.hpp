@@ -28,7 +28,7 @@ PT_DEV float wave_read(float x, int src)
 // Bytes of LDS stage_scene<false>() fills, rounded up to 16 (device-side twin of scene_lds_bytes).
 PT_DEV uint32_t scene_lds_bytes_dev(const SceneParams &s)
 {
-    const uint32_t n = s.n_prims * 32u + s.n_mats * 20u + s.n_lights * 16u;
+    const uint32_t n = s.n_prims * 32u + s.n_mats * 24u + s.n_lights * 16u;
     return (n + 15u) & ~15u;
 }
 
@@ -36,7 +36,7 @@ struct SceneView {
     const float4 *sph;   // LDS: all spheres (resident) or the current tile (streaming)
     const float4 *aux;   // (1/radius, materialId bits, lightId bits, radius)
     const float4 *mat;   // (r, g, b, coef)
-    const int *mat_type;
+    const int2 *mat_type;   // (MaterialType, bits of 1.f / coef)
     const float4 *light; // (r, g, b, -)
 };
 
@@ -51,7 +51,7 @@ PT_DEV SceneView stage_scene(const SceneParams &p, unsigned char *lds_raw, int t
         float4 *lds_aux = lds_sph + p.n_prims;
         float4 *lds_mat = lds_aux + p.n_prims;
         float4 *lds_light = lds_mat + p.n_mats;
-        int *lds_type = reinterpret_cast<int *>(lds_light + p.n_lights);
+        int2 *lds_type = reinterpret_cast<int2 *>(lds_light + p.n_lights);
         for (uint32_t i = tid; i < p.n_prims; i += kBlockThreads) {
             lds_sph[i] = p.sph[i];
             lds_aux[i] = p.aux[i];
@@ -541,9 +541,9 @@ PT_DEV bool shade_bounce(const SceneView &sc, float4 s, int best, float t, uint3
     uint32_t r[4];
     philox4x32_10(pix, it, (uint32_t)b, STREAM_PATH, k0, k1, r);
     const float4 m = sc.mat[mat_id];
-    const int mtype = sc.mat_type[mat_id];
+    const int2 mt = sc.mat_type[mat_id];
     float pdf;
-    const V3 f = sample_material(mtype, mk(m.x, m.y, m.z), m.w, wo, d, pdf, n, u01(r[0]), u01(r[1]));
+    const V3 f = sample_material(mt.x, mk(m.x, m.y, m.z), m.w, __int_as_float(mt.y), wo, d, pdf, n, u01(r[0]), u01(r[1]));
     // pathtracer.cu:146-161
     if ((f.x == 0.f && f.y == 0.f && f.z == 0.f) || pdf == 0.f) return true;
     PT_LS(7);
