@@ -265,7 +265,8 @@ struct BvhTraversal {
 // constants.  Returns false when there is nothing to traverse (NaN in the ray).
 PT_DEV bool bvh_begin(const BvhParams &B, V3 o, V3 d, float &tmax, int &best, BvhTraversal &tr)
 {
-    for (uint32_t i = 0; i < B.n_big; ++i) sphere_test_lex(B.big_sph[i], B.big_index[i], o, d, tmax, best);
+    // best is -1 on entry and big_index ascends: the strict rule of the scan gives the lexicographic minimum
+    for (uint32_t i = 0; i < B.n_big; ++i) sphere_test(B.big_sph[i], B.big_index[i], o, d, tmax, best);
     const float cx = o.x - B.centre[0], cy = o.y - B.centre[1], cz = o.z - B.centre[2];
     const float L = __builtin_amdgcn_sqrtf(cx * cx + cy * cy + cz * cz) * 1.000002f + B.half_diag;
     const float excess = (d.x * d.x + d.y * d.y + d.z * d.z) - 1.f;

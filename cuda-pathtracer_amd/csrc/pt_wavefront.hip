@@ -237,6 +237,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
     const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
 
     bool has = false, trav = false, over = false, exhausted = false;
+    bool start = false;                 // the lane has a new ray whose traversal is not set up yet
     V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f), T = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
     uint32_t pix = 0, it_sub = 0;
     int bounce = p.bounce;              // WHOLE: per lane
@@ -287,14 +288,20 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
                 }
                 if (has) {
                     if (WHOLE) bounce = p.bounce;
-                    tmax = PT_INF;
-                    best = -1;
-                    over = false;
-                    trav = bvh_begin(B, o, d, tmax, best, tr);
+                    start = true;
                 }
             }
         }
         if (!__any(has)) break;
+        // One set-up (the always-tested spheres, the ray's slab constants) for the fetched rays and
+        // for the paths that continue in their lane: two call sites would run one after the other.
+        if (start) {
+            start = false;
+            tmax = PT_INF;
+            best = -1;
+            over = false;
+            trav = bvh_begin(B, o, d, tmax, best, tr);
+        }
 
         // ---- traverse until too few lanes are busy ---------------------------------------------
         for (;;) {
@@ -331,10 +338,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
             if (WHOLE && cont) {   // the same lane traces the path's next ray
                 bounce = b;
                 has = true;
-                tmax = PT_INF;
-                best = -1;
-                over = false;
-                trav = bvh_begin(B, o, d, tmax, best, tr);
+                start = true;
             }
         }
         const unsigned long long mask = __ballot(cont);
