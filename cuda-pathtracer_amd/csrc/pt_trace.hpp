@@ -333,21 +333,25 @@ PT_DEV bool bvh_node_step(const BvhParams &B, const uint4 *nodes, const Stack &s
                     slab_test(qplane_hi(q0.y), qplane_hi(q0.w), qplane_hi(q1.y), qplane_hi(q1.w), qplane_hi(q2.y), qplane_hi(q2.w),
                                  tr.ray, tmax, t3);
     ++tr.visits;
-    // nearest hit child (NaN entry distances lose against everything, which is fine: they are only a visiting order)
-    int near_slot = -1;
-    float near_t = PT_INF;
-    if (h0) { near_slot = 0; near_t = t0; }
-    if (h1 && (near_slot < 0 || t1 < near_t)) { near_slot = 1; near_t = t1; }
-    if (h2 && (near_slot < 0 || t2 < near_t)) { near_slot = 2; near_t = t2; }
-    if (h3 && (near_slot < 0 || t3 < near_t)) { near_slot = 3; near_t = t3; }
-    if (near_slot < 0) return bvh_pop(stack, tr.sp, tmax, tr.cur);
-    const int n_defer = (int)h0 + (int)h1 + (int)h2 + (int)h3 - 1;
-    if (tr.sp + n_defer > (int)B.depth) { tr.visits = 0xffffffffu; return true; }
-    if (h0 && near_slot != 0) { stack.push(tr.sp, c0, t0); ++tr.sp; }
-    if (h1 && near_slot != 1) { stack.push(tr.sp, c1, t1); ++tr.sp; }
-    if (h2 && near_slot != 2) { stack.push(tr.sp, c2, t2); ++tr.sp; }
-    if (h3 && near_slot != 3) { stack.push(tr.sp, c3, t3); ++tr.sp; }
-    tr.cur = near_slot == 0 ? c0 : (near_slot == 1 ? c1 : (near_slot == 2 ? c2 : c3));
+    if (!(h0 || h1 || h2 || h3)) return bvh_pop(stack, tr.sp, tmax, tr.cur);
+    // The nearest hit child, the lowest slot among equal distances (only a visiting order: a NaN
+    // distance would count as nearest).  Some hit child always qualifies: the minimum itself.
+    const float e0 = h0 ? t0 : PT_INF, e1 = h1 ? t1 : PT_INF, e2 = h2 ? t2 : PT_INF, e3 = h3 ? t3 : PT_INF;
+    const float emin = __builtin_fminf(__builtin_fminf(e0, e1), __builtin_fminf(e2, e3));
+    const bool n0 = h0 && !(e0 > emin);
+    const bool n1 = h1 && !n0 && !(e1 > emin);
+    const bool n2 = h2 && !(n0 || n1) && !(e2 > emin);
+    const bool n3 = h3 && !(n0 || n1 || n2);
+    const bool d0 = h0 && !n0, d1 = h1 && !n1, d2 = h2 && !n2, d3 = h3 && !n3;   // deferred
+    if (tr.sp + 3 > (int)B.depth) {   // near the top of the stack: count what this node adds
+        const int n_defer = (int)d0 + (int)d1 + (int)d2 + (int)d3;
+        if (tr.sp + n_defer > (int)B.depth) { tr.visits = 0xffffffffu; return true; }
+    }
+    if (d0) { stack.push(tr.sp, c0, t0); ++tr.sp; }
+    if (d1) { stack.push(tr.sp, c1, t1); ++tr.sp; }
+    if (d2) { stack.push(tr.sp, c2, t2); ++tr.sp; }
+    if (d3) { stack.push(tr.sp, c3, t3); ++tr.sp; }
+    tr.cur = n0 ? c0 : (n1 ? c1 : (n2 ? c2 : c3));
     return true;
 }
 
