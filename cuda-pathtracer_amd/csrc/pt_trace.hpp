@@ -154,8 +154,13 @@ PT_DEV void sphere_test_lex(float4 s, int index, V3 o, V3 d, float &tmax, int &b
 // moves away from is dropped (its t is replaced by 3e38: "never leaves").  The fused multiply-add
 // rounds once; what k loses to the large constant is below half a grid step, which the builder's
 // outward rounding covers.
+// The ray enters a slab through its lower plane where the direction component is >= 0 and through
+// its upper plane where it is negative, so the two planes are told apart once per ray (`neg`, bit
+// k for axis k) and a box costs one max3 and one min3 instead of a min and a max per axis:
+// (inv_n, kn) belong to the plane of entry, (inv_f, kf) to the plane of exit.
 struct BvhRay {
-    V3 inv_lo, inv_hi, klo, khi;
+    V3 inv_n, inv_f, kn, kf;
+    uint32_t neg;
 };
 
 // The two 16-bit grid coordinates of a node word as the floats 2^23 + q.
@@ -165,16 +170,15 @@ PT_DEV float qplane_hi(uint32_t w) { return __uint_as_float(__builtin_amdgcn_ali
 // Slab test of one child box against the ray.  The fused multiply-adds are deliberate: this
 // arithmetic only decides which boxes are visited (its rounding is covered by the widening),
 // it never reaches a result.  NaN-conservative: the negated comparisons enter on NaN.
-PT_DEV bool slab_test(float lx, float ly, float lz, float hx, float hy, float hz, const BvhRay &r, float tmax,
+// (nx, ny, nz): the planes of entry, (fx, fy, fz): the planes of exit.
+PT_DEV bool slab_test(float nx, float ny, float nz, float fx, float fy, float fz, const BvhRay &r, float tmax,
                       float &tnear)
 {
-    const float t1x = __builtin_fmaf(lx, r.inv_lo.x, r.klo.x), t2x = __builtin_fmaf(hx, r.inv_hi.x, r.khi.x);
-    const float t1y = __builtin_fmaf(ly, r.inv_lo.y, r.klo.y), t2y = __builtin_fmaf(hy, r.inv_hi.y, r.khi.y);
-    const float t1z = __builtin_fmaf(lz, r.inv_lo.z, r.klo.z), t2z = __builtin_fmaf(hz, r.inv_hi.z, r.khi.z);
-    tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
-                            __builtin_fminf(t1z, t2z));
-    const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
-                                       __builtin_fmaxf(t1z, t2z));
+    const float t1x = __builtin_fmaf(nx, r.inv_n.x, r.kn.x), t2x = __builtin_fmaf(fx, r.inv_f.x, r.kf.x);
+    const float t1y = __builtin_fmaf(ny, r.inv_n.y, r.kn.y), t2y = __builtin_fmaf(fy, r.inv_f.y, r.kf.y);
+    const float t1z = __builtin_fmaf(nz, r.inv_n.z, r.kn.z), t2z = __builtin_fmaf(fz, r.inv_f.z, r.kf.z);
+    tnear = __builtin_fmaxf(__builtin_fmaxf(t1x, t1y), t1z);
+    const float tfar = __builtin_fminf(__builtin_fminf(t2x, t2y), t2z);
     return !(tnear > tfar) && !(tfar < 0.f) && !(tnear > tmax);
 }
 
@@ -301,8 +305,20 @@ PT_DEV bool bvh_begin(const BvhParams &B, V3 o, V3 d, float &tmax, int &best, Bv
             else               { ih[ax] = 0.f; kh[ax] = 3.0e38f; }
         }
     }
-    tr.ray.inv_lo = mk(il[0], il[1], il[2]); tr.ray.inv_hi = mk(ih[0], ih[1], ih[2]);
-    tr.ray.klo = mk(kl[0], kl[1], kl[2]);    tr.ray.khi = mk(kh[0], kh[1], kh[2]);
+    // plane of entry: the lower one for a direction component >= 0 (its bound is the lower bound on t
+    // in the narrow case |d| <= s as well, where the other plane's has been dropped), else the upper one
+    float in_[3], if_[3], kn_[3], kf_[3];
+    uint32_t neg = 0;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const bool ng = dir[ax] < 0.f;
+        in_[ax] = ng ? ih[ax] : il[ax]; kn_[ax] = ng ? kh[ax] : kl[ax];
+        if_[ax] = ng ? il[ax] : ih[ax]; kf_[ax] = ng ? kl[ax] : kh[ax];
+        neg |= ng ? (1u << ax) : 0u;
+    }
+    tr.ray.inv_n = mk(in_[0], in_[1], in_[2]); tr.ray.inv_f = mk(if_[0], if_[1], if_[2]);
+    tr.ray.kn = mk(kn_[0], kn_[1], kn_[2]);    tr.ray.kf = mk(kf_[0], kf_[1], kf_[2]);
+    tr.ray.neg = neg;
     tr.cur = 0; tr.sp = 0; tr.visits = 0;
     // a NaN in the origin or the direction makes every sphere test fail (all comparisons false)
     return !(excess != excess || L != L);
@@ -322,15 +338,20 @@ PT_DEV bool bvh_node_step(const BvhParams &B, const uint4 *nodes, const Stack &s
     const int c0 = (int)rf.x, c1 = (int)rf.y, c2 = (int)rf.z, c3 = (int)rf.w;
     float t0, t1, t2, t3;
     // words: q0 = (lo.x c0|c1, lo.x c2|c3, lo.y c0|c1, lo.y c2|c3), q1 = (lo.z, lo.z, hi.x, hi.x), q2 = (hi.y, hi.y, hi.z, hi.z)
-    const bool h0 = slab_test(qplane_lo(q0.x), qplane_lo(q0.z), qplane_lo(q1.x), qplane_lo(q1.z), qplane_lo(q2.x), qplane_lo(q2.z),
+    // planes of entry and exit per axis: the lower and the upper plane's words, swapped where the ray runs backwards
+    const bool gx = (tr.ray.neg & 1u) != 0u, gy = (tr.ray.neg & 2u) != 0u, gz = (tr.ray.neg & 4u) != 0u;
+    const uint32_t nx01 = gx ? q1.z : q0.x, nx23 = gx ? q1.w : q0.y, fx01 = gx ? q0.x : q1.z, fx23 = gx ? q0.y : q1.w;
+    const uint32_t ny01 = gy ? q2.x : q0.z, ny23 = gy ? q2.y : q0.w, fy01 = gy ? q0.z : q2.x, fy23 = gy ? q0.w : q2.y;
+    const uint32_t nz01 = gz ? q2.z : q1.x, nz23 = gz ? q2.w : q1.y, fz01 = gz ? q1.x : q2.z, fz23 = gz ? q1.y : q2.w;
+    const bool h0 = slab_test(qplane_lo(nx01), qplane_lo(ny01), qplane_lo(nz01), qplane_lo(fx01), qplane_lo(fy01), qplane_lo(fz01),
                                  tr.ray, tmax, t0);   // slots 0 and 1 are always used
-    const bool h1 = slab_test(qplane_hi(q0.x), qplane_hi(q0.z), qplane_hi(q1.x), qplane_hi(q1.z), qplane_hi(q2.x), qplane_hi(q2.z),
+    const bool h1 = slab_test(qplane_hi(nx01), qplane_hi(ny01), qplane_hi(nz01), qplane_hi(fx01), qplane_hi(fy01), qplane_hi(fz01),
                                  tr.ray, tmax, t1);
     const bool h2 = c2 != 0x7fffffff &&
-                    slab_test(qplane_lo(q0.y), qplane_lo(q0.w), qplane_lo(q1.y), qplane_lo(q1.w), qplane_lo(q2.y), qplane_lo(q2.w),
+                    slab_test(qplane_lo(nx23), qplane_lo(ny23), qplane_lo(nz23), qplane_lo(fx23), qplane_lo(fy23), qplane_lo(fz23),
                                  tr.ray, tmax, t2);
     const bool h3 = c3 != 0x7fffffff &&
-                    slab_test(qplane_hi(q0.y), qplane_hi(q0.w), qplane_hi(q1.y), qplane_hi(q1.w), qplane_hi(q2.y), qplane_hi(q2.w),
+                    slab_test(qplane_hi(nx23), qplane_hi(ny23), qplane_hi(nz23), qplane_hi(fx23), qplane_hi(fy23), qplane_hi(fz23),
                                  tr.ray, tmax, t3);
     ++tr.visits;
     if (!(h0 || h1 || h2 || h3)) return bvh_pop(stack, tr.sp, tmax, tr.cur);
