@@ -209,9 +209,10 @@ PT_DEV float bvh_inverse(float x)
 // deferred child reference and the distance at which the ray enters its box.
 template <int STRIDE>
 struct BvhStack8 {
-    uint2 *base;   // this lane's column
-    PT_DEV void push(int sp, int ref, float t) const { base[sp * STRIDE] = make_uint2((uint32_t)ref, __float_as_uint(t)); }
-    PT_DEV void read(int sp, int &ref, float &t) const { const uint2 v = base[sp * STRIDE]; ref = (int)v.x; t = __uint_as_float(v.y); }
+    uint32_t *base;   // this lane's column: entry k is the words [2k][lane] (child) and [2k + 1][lane] (distance),
+                      // two conflict-free dword accesses a constant 4 * STRIDE bytes apart (no 64-bit register pair to build)
+    PT_DEV void push(int sp, int ref, float t) const { base[2 * sp * STRIDE] = (uint32_t)ref; base[(2 * sp + 1) * STRIDE] = __float_as_uint(t); }
+    PT_DEV void read(int sp, int &ref, float &t) const { ref = (int)base[2 * sp * STRIDE]; t = __uint_as_float(base[(2 * sp + 1) * STRIDE]); }
 };
 // Pops deferred boxes until one can still hold a hit at or below tmax; false when none is left.
 template <class Stack>
@@ -423,7 +424,7 @@ PT_DEV void intersect_bvh(const BvhParams &B, const float4 *sph, uint32_t n_prim
                           bool active, V3 o, V3 d, float &tmax, int &best)
 {
     BvhStack8<kBlockThreads> stack;
-    stack.base = stack_lds + tid;
+    stack.base = reinterpret_cast<uint32_t *>(stack_lds) + tid;
     BvhTraversal tr;
     bool more = false;
     if (active) more = bvh_begin(B, o, d, tmax, best, tr);

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
     const BvhParams &B = p.scene.bvh;
     const SceneView sc = stage_scene<true>(p.scene, lds_raw, tid);
     BvhStack8<BT> stack;   // LDS: [stack entries][BT lanes]
-    stack.base = reinterpret_cast<uint2 *>(lds_raw) + tid;
+    stack.base = reinterpret_cast<uint32_t *>(lds_raw) + tid;
     const uint4 *nodes = B.nodes;
     const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
 
