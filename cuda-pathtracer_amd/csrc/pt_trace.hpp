@@ -377,6 +377,34 @@ PT_DEV bool bvh_node_step(const BvhParams &B, const uint4 *nodes, const Stack &s
     return true;
 }
 
+// While a traversal runs, a hit inside a leaf is remembered as the leaf slot it sits in (tagged
+// with kLeafSlotTag), not as the sphere's index: the slot's index is needed only for the winner
+// and for breaking exact ties, so the leaf step does not load the leaf's four indices (64 instead
+// of 80 bytes per leaf visit).  bvh_sphere_index turns either form into the sphere's index.
+constexpr int kLeafSlotTag = 0x40000000;
+PT_DEV int bvh_sphere_index(const BvhParams &B, int x)
+{
+    return (x >= 0 && (x & kLeafSlotTag)) ? reinterpret_cast<const int *>(B.leaf_index)[x & ~kLeafSlotTag] : x;
+}
+
+// sphere_test_lex for the sphere in leaf slot `slot` (tagged).
+PT_DEV void sphere_test_slot(const BvhParams &B, float4 s, int slot, V3 o, V3 d, float &tmax, int &best)
+{
+    const float opx = s.x - o.x, opy = s.y - o.y, opz = s.z - o.z;
+    const float b = opx * d.x + opy * d.y + opz * d.z;
+    const float det = b * b - (opx * opx + opy * opy + opz * opz) + s.w;
+    if (!(det < 0.f)) {
+        const float sq = pt_sqrt(det);
+        float t = b - sq;
+        if (!(t > PT_EPSILON)) t = b + sq;
+        if (t > PT_EPSILON) {
+            bool take = t < tmax;
+            if (t == tmax && best >= 0) take = bvh_sphere_index(B, slot) < bvh_sphere_index(B, best);   // rare
+            if (take) { tmax = t; best = slot; }
+        }
+    }
+}
+
 // One leaf (tr.cur < 0): its four sphere slots, then the next deferred box.
 template <class Stack>
 PT_DEV bool bvh_leaf_step(const BvhParams &B, const Stack &stack, V3 o, V3 d, float &tmax, int &best, BvhTraversal &tr)
@@ -385,11 +413,11 @@ PT_DEV bool bvh_leaf_step(const BvhParams &B, const Stack &stack, V3 o, V3 d, fl
     const uint32_t leaf = (uint32_t)~tr.cur;
     const float4 *S = B.leaf_sph + 4 * (size_t)leaf;
     const float4 s0 = S[0], s1 = S[1], s2 = S[2], s3 = S[3];
-    const int4 id = B.leaf_index[leaf];
-    sphere_test_lex(s0, id.x, o, d, tmax, best);
-    sphere_test_lex(s1, id.y, o, d, tmax, best);
-    sphere_test_lex(s2, id.z, o, d, tmax, best);
-    sphere_test_lex(s3, id.w, o, d, tmax, best);
+    const int slot = (int)(leaf * 4u) | kLeafSlotTag;
+    sphere_test_slot(B, s0, slot, o, d, tmax, best);
+    sphere_test_slot(B, s1, slot + 1, o, d, tmax, best);
+    sphere_test_slot(B, s2, slot + 2, o, d, tmax, best);
+    sphere_test_slot(B, s3, slot + 3, o, d, tmax, best);
     ++tr.visits;
     return bvh_pop(stack, tr.sp, tmax, tr.cur);
 }
@@ -454,6 +482,7 @@ PT_DEV void intersect_bvh(const BvhParams &B, const float4 *sph, uint32_t n_prim
             more = bvh_leaf_step(B, stack, o, d, tmax, best, tr);
         }
     }
+    best = bvh_sphere_index(B, best);
     bvh_finish_over_budget(sph, n_prims, over_budget, o, d, tmax, best);
 #ifdef PT_BVH_STATS
     if (active) {

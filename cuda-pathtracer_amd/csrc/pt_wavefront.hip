@@ -323,6 +323,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
         const bool fin = has && !trav;
         PT_LS(4);
         if (fin) PT_LS(17);
+        if (fin) best = bvh_sphere_index(B, best);
         bvh_finish_over_budget(p.scene.sph, p.scene.n_prims, fin && over, o, d, tmax, best);
         bool cont = false;
         if (fin) {
