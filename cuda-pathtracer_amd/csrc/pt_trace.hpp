@@ -147,17 +147,16 @@ PT_DEV void sphere_test_lex(float4 s, int index, V3 o, V3 d, float &tmax, int &b
 //     t * (d + s) >= lo - a - o   and   t * (d - s) <= hi + a - o,
 // so the two planes get different slopes: t(lower plane) = (2^23 + q) * inv_lo + klo with inv_lo =
 // step / (d + s), klo = (origin - a - o) / (d + s) - 2^23 * inv_lo, and t(upper plane) likewise with
-// d - s and + a.  For |d| > s the smaller of the two is where the ray enters the slab and the larger
-// where it leaves it (when the pair comes out in the other order both are negative, and the box is
-// dropped as lying behind the origin either way).  For |d| <= s the slab grows at least as fast as
-// the ray moves across it: both conditions are lower bounds on t, and the one of the plane the ray
-// moves away from is dropped (its t is replaced by 3e38: "never leaves").  The fused multiply-add
-// rounds once; what k loses to the large constant is below half a grid step, which the builder's
-// outward rounding covers.
-// The ray enters a slab through its lower plane where the direction component is >= 0 and through
-// its upper plane where it is negative, so the two planes are told apart once per ray (`neg`, bit
-// k for axis k) and a box costs one max3 and one min3 instead of a min and a max per axis:
-// (inv_n, kn) belong to the plane of entry, (inv_f, kf) to the plane of exit.
+// d - s and + a.  For d > s the lower plane's t bounds t from below (the ray enters there) and the
+// upper plane's from above (it leaves there); for d < -s the divisions by negative numbers turn
+// both around.  For |d| <= s the slab grows at least as fast as the ray moves across it: both
+// conditions are lower bounds on t, and the one of the plane the ray moves away from is dropped
+// (its t is replaced by 3e38: "never leaves").  In every case the plane of entry is the lower one
+// where the direction component is >= 0 and the upper one where it is negative, so the two are told
+// apart once per ray (`neg`, bit k for axis k) and a box costs one max3 and one min3 instead of a
+// min and a max per axis: (inv_n, kn) belong to the plane of entry, (inv_f, kf) to the plane of
+// exit.  The fused multiply-add rounds once; what k loses to the large constant is below half a
+// grid step, which the builder's outward rounding covers.
 struct BvhRay {
     V3 inv_n, inv_f, kn, kf;
     uint32_t neg;
