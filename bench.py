@@ -357,6 +357,10 @@ def main():
             dist.all_reduce(t, op=op)
         return float(t.item())
 
+    if grouped and backend == "nccl":
+        # RCCL sets up its channels on a communicator's first collective of a kind: one untimed
+        # reduce of a (still zero) frame-sized buffer, whatever --warmup says
+        sharding.reduce_to_root(bufs[-1], dist, 0, single_rank_too=True)
     for _ in range(args.warmup):
         step()
     fence()
