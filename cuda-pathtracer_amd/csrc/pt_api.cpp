@@ -82,6 +82,7 @@ struct pt_context {
     int last_launch;             // PT_LAUNCH_* of the last render
     uint32_t wf_sub_capacity;   // paths per sub-queue the buffers were sized for
     uint64_t wf_capacity;       // paths per batch the buffers were sized for
+    uint64_t wf_mask_bytes;     // size of the path pool's mask behind a set's counters (0: none)
     std::string error;
 };
 
@@ -208,6 +209,7 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->last_launch = PT_LAUNCH_NONE;
     h->wf_sub_capacity = 0;
     h->wf_capacity = 0;
+    h->wf_mask_bytes = 0;
 
     if (hipMalloc((void **)&h->d_ray_counter, sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(h->d_ray_counter, 0, sizeof(unsigned long long)) != hipSuccess ||
@@ -311,7 +313,7 @@ static void free_wavefront(pt_context *h)
         if (pipe.resolved) (void)hipEventDestroy(pipe.resolved);
     }
     memset(h->wf_pipe, 0, sizeof h->wf_pipe);
-    h->wf_sub_capacity = 0; h->wf_capacity = 0;
+    h->wf_sub_capacity = 0; h->wf_capacity = 0; h->wf_mask_bytes = 0;
     h->wf_n_queues = 0;
 }
 
@@ -673,6 +675,8 @@ static uint64_t wavefront_sub_capacity(uint32_t w, uint32_t h, uint64_t iteratio
     return (blocks + kWfSubQueues - 1) / kWfSubQueues * 256;
 }
 static uint64_t wavefront_bytes_per_path(int mode);
+static uint64_t wavefront_mask_bytes(int mode, uint64_t paths);
+static uint64_t wavefront_queues(int mode);
 
 int pt_set_memory_limit(pt_handle h, uint64_t bytes)
 {
@@ -692,7 +696,7 @@ int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
     const uint64_t counts = (uint64_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
     const uint64_t queue_bytes = 2 * sizeof(float4) + sizeof(WavefrontTail);
     const uint64_t wf_set = (uint64_t)h->wf_n_queues * h->wf_sub_capacity * kWfSubQueues * queue_bytes +
-                            h->wf_capacity * 3 * sizeof(float) + counts;
+                            h->wf_capacity * 3 * sizeof(float) + counts + h->wf_mask_bytes;
     const uint64_t wf_now = ((h->wf_pipe[0].counts ? 1 : 0) + (h->wf_pipe[1].counts ? 1 : 0)) * wf_set;
     bytes[0] = fixed + steal_now + tickets_now + wf_now;
     // what the next render adds: wavefront queues of one batch, or the scratch pool and tickets
@@ -704,8 +708,9 @@ int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
     if (n_iterations && h->scene_ready && paths_per_it && takes_wavefront(h, h->iteration + (uint64_t)n_iterations, n_iterations) && batch_it > 0) {
         const uint64_t capacity = paths_per_it * batch_it;
         const uint64_t sub_cap = wavefront_sub_capacity(h->camera.width, owned_rows(h), batch_it);
-        const uint64_t n_queues = (wavefront_bytes_per_path(wf_mode) - 3 * sizeof(float)) / queue_bytes;
-        const uint64_t need = wf_sets * (n_queues * sub_cap * kWfSubQueues * queue_bytes + capacity * 3 * sizeof(float) + counts);
+        const uint64_t n_queues = wavefront_queues(wf_mode);
+        const uint64_t need = wf_sets * (n_queues * sub_cap * kWfSubQueues * queue_bytes + capacity * 3 * sizeof(float) + counts +
+                                         wavefront_mask_bytes(wf_mode, capacity));
         if (need > wf_next) wf_next = need;
     } else if (n_iterations && h->scene_ready && !h->wavefront && h->steal && !h->steal_alloc_failed &&
                (!h->memory_limit || kStealPoolBytes + kStealMaskBytes <= h->memory_limit)) {
@@ -812,10 +817,14 @@ static int wavefront_mode(const pt_context *h, uint32_t n_iterations)
     return wavefront_whole_paths(h);
 }
 
+// The path pool also keeps one mask byte per pixel-iteration (which of its four paths have an
+// entry in the radiance buffer): a quarter of a byte per path, planned as one.
 static uint64_t wavefront_bytes_per_path(int mode)
 {
-    return (mode == 0 ? 2 : mode == 2 ? 1 : 0) * kWfQueueRecord + 3 * sizeof(float);
+    return (mode == 0 ? 2 : mode == 2 ? 1 : 0) * kWfQueueRecord + 3 * sizeof(float) + (mode == 3 ? 1 : 0);
 }
+static uint64_t wavefront_mask_bytes(int mode, uint64_t paths) { return mode == 3 ? (paths / 4 + 3) / 4 * 4 : 0; }
+static uint64_t wavefront_queues(int mode) { return mode == 0 ? 2 : mode == 2 ? 1 : 0; }
 
 // Iterations per wavefront batch of a frame with `paths_per_it` paths per iteration, within the
 // handle's memory limit; 0 when not even one iteration fits.  A render of more iterations than
@@ -842,7 +851,10 @@ static uint32_t plan_batches(uint64_t paths_per_it, uint32_t n_iterations, uint6
 
 static uint32_t wavefront_batch_iterations(const pt_context *h, int mode, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets = nullptr)
 {
-    return plan_batches(paths_per_it, n_iterations, wavefront_bytes_per_path(mode), h->memory_limit, h->wf_target_mpaths, sets);
+    // the path pool's batches keep the size measured best (kWfTargetBytes over its 12 bytes of radiance per path)
+    const uint32_t target_mpaths = h->wf_target_mpaths ? h->wf_target_mpaths
+                                 : mode == 3 ? (uint32_t)(kWfTargetBytes / (3 * sizeof(float)) >> 20) : 0;
+    return plan_batches(paths_per_it, n_iterations, wavefront_bytes_per_path(mode), h->memory_limit, target_mpaths, sets);
 }
 
 int pt_debug_plan_batches(uint32_t width, uint32_t height, uint32_t band_rows, uint32_t band_rank, uint32_t band_world,
@@ -866,18 +878,22 @@ int pt_debug_plan_batches(uint32_t width, uint32_t height, uint32_t band_rows, u
 // they suffice).  A failed allocation frees what was allocated and reports PT_ERR_NOMEM.
 static int ensure_wavefront(pt_context *h, int mode, uint64_t capacity, uint64_t sub_cap64, uint32_t sets, size_t *counts_bytes_out)
 {
-    const int n_queues = (int)((wavefront_bytes_per_path(mode) - 3 * sizeof(float)) / kWfQueueRecord);
+    const int n_queues = (int)wavefront_queues(mode);
+    const uint64_t mask_bytes = wavefront_mask_bytes(mode, capacity);
     if (sub_cap64 > 0xffffff00ull) return fail(h, PT_ERR_INVALID, "wavefront variant: image too large");
     const uint32_t sub_cap = (uint32_t)sub_cap64;
-    const size_t counts_bytes = (size_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
+    // the counters, and behind them the path pool's mask: both zero between batches
+    const size_t counters_bytes = (size_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
+    bool have = capacity <= h->wf_capacity && sub_cap <= h->wf_sub_capacity && h->wf_n_queues >= n_queues &&
+                mask_bytes <= h->wf_mask_bytes;
+    for (uint32_t k = 0; k < sets; ++k) have = have && h->wf_pipe[k].counts;
+    const size_t counts_bytes = counters_bytes + (size_t)(have ? h->wf_mask_bytes : mask_bytes);
     *counts_bytes_out = counts_bytes;
     if (sets > 1 && !h->wf_stream2) {
         if (hipStreamCreateWithFlags(&h->wf_stream2, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->wf_fork, hipEventDisableTiming) != hipSuccess)
             return fail(h, PT_ERR_DEVICE, "wavefront variant: cannot create the second stream");
     }
-    bool have = capacity <= h->wf_capacity && sub_cap <= h->wf_sub_capacity && h->wf_n_queues >= n_queues;
-    for (uint32_t k = 0; k < sets; ++k) have = have && h->wf_pipe[k].counts;
     if (!have) {
         PT_HIP(h, hipStreamSynchronize(h->stream));
         free_wavefront(h);
@@ -904,6 +920,7 @@ static int ensure_wavefront(pt_context *h, int mode, uint64_t capacity, uint64_t
         h->wf_capacity = capacity;
         h->wf_sub_capacity = sub_cap;
         h->wf_n_queues = n_queues;
+        h->wf_mask_bytes = mask_bytes;
     }
     return PT_OK;
 }
@@ -930,6 +947,7 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, int mode, s
     pt_context::WfPipe &pipe = h->wf_pipe[set];
     p.counts = pipe.counts;
     p.path_radiance = pipe.radiance;
+    p.path_mask = pipe.counts + (size_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride;
     // the resolve kernel leaves the counters at zero for the set's next batch
     if (pipe.counts_dirty) PT_HIP(h, hipMemsetAsync(pipe.counts, 0, counts_bytes, stream));
     pipe.counts_dirty = true;
@@ -1370,6 +1388,7 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
         p.buffer = nullptr;
         p.ray_counter = d_cnt;
         p.hit_ids = d_hits; p.pixel_rgb = d_rgb;
+        p.store_all_paths = 1;   // `radiance` is read for every path
         rc = launch_wavefront_batch(h, p, mode, counts_bytes, 0, h->stream, nullptr);
         if (rc != PT_OK) goto cleanup;
         // the batch's per-path radiance buffer has the layout of `radiance`

@@ -178,7 +178,11 @@ struct WavefrontParams {
     uint32_t *counts;           // [max_bounces + 2][kWfSubQueues][kWfCountStride]: word 0 = paths alive
                                 // in sub-queue q entering bounce k, word 1 = fetch cursor of the
                                 // dynamic-fetch kernel over those paths
-    float *path_radiance;       // [paths][3], zero when the batch starts (the path pool stores every entry)
+    float *path_radiance;       // [paths][3], zero when the batch starts.  The path pool needs no zeroed buffer:
+                                // it stores the entries of the paths that collected light and marks them in path_mask
+    uint32_t *path_mask;        // path pool: one byte per pixel-iteration of the batch, bit s = sub-sample s has an
+                                // entry in path_radiance; zero when the batch starts, left at zero by the resolve
+    int store_all_paths;        // path pool, parity hook: black paths are stored and marked too
     // resolve
     int accum_mode, overwrite;
     float *buffer;              // may be NULL (parity hook)

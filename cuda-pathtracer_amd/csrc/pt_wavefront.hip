@@ -490,9 +490,14 @@ __global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontP
                 bool end = true;
                 record_hit(p, n_pix, pix, it_sub, b, best);
                 if (best >= 0) end = shade_bounce(sc, (TILED ? p.scene.sph : sc.sph)[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
-                if (end) {   // the path lived in this lane from its camera ray on: one store, no zeroed buffer needed
-                    float *pr = p.path_radiance + batch_path_index(p, n_pix, pix, it_sub) * 3;
+                // The path lived in this lane from its camera ray on: one store when it ends, and only
+                // if it met a light -- most paths end black, and adding their +0 changes no sum.
+                if (end && (L.x != 0.f || L.y != 0.f || L.z != 0.f || p.store_all_paths)) {
+                    const size_t path = batch_path_index(p, n_pix, pix, it_sub);
+                    float *pr = p.path_radiance + path * 3;
                     pr[0] = L.x; pr[1] = L.y; pr[2] = L.z;
+                    // byte (path >> 2) of the mask, bit (path & 3)
+                    atomicOr(p.path_mask + (path >> 4), 1u << ((uint32_t)(path & 15u) >> 2 << 3 | (uint32_t)(path & 3u)));
                 }
                 cont = !end;
                 has = cont;
@@ -516,10 +521,23 @@ __global__ __launch_bounds__(kBlockThreads) void wf_resolve_kernel(const Wavefro
         V3 acc = (p.overwrite || !px) ? mk(0.f, 0.f, 0.f) : mk(px[0], px[1], px[2]);
         V3 cpix = mk(0.f, 0.f, 0.f);
         for (uint32_t k = 0; k < p.n_iterations; ++k) {
-            const float *pr = p.path_radiance + (((size_t)k * n_pix + local) << 2) * 3;
+            const size_t group = (size_t)k * n_pix + local;
+            const float *pr = p.path_radiance + (group << 2) * 3;
             V3 c = mk(0.f, 0.f, 0.f);
+            if (p.path_pool) {
+                // only the marked sub-samples have an entry; the others were black (c + 0 == c)
+                unsigned char *mask = reinterpret_cast<unsigned char *>(p.path_mask) + group;
+                const uint32_t m = *mask;
+                if (m) {
+                    *mask = 0;   // for the buffer set's next batch
 #pragma unroll
-            for (int s = 0; s < 4; ++s) c = c + mk(pr[s * 3], pr[s * 3 + 1], pr[s * 3 + 2]);
+                    for (int s = 0; s < 4; ++s)
+                        if (m & (1u << s)) c = c + mk(pr[s * 3], pr[s * 3 + 1], pr[s * 3 + 2]);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) c = c + mk(pr[s * 3], pr[s * 3 + 1], pr[s * 3 + 2]);
+            }
             acc = accumulate_pixel(acc, c, p.first_iteration + k, p.accum_mode, &cpix);
         }
         if (px) { px[0] = acc.x; px[1] = acc.y; px[2] = acc.z; }
