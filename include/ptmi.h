@@ -161,7 +161,8 @@ int pt_reset_counters(pt_handle h);
  *     memory limit (row bands included: the batch then holds the owned rows only): PT_VARIANT_WAVEFRONT for scenes rendered through the
  *     sphere BVH; the path pool for scenes rendered by the linear scan: persistent waves
  *     whose lanes take the next camera ray of the batch, whatever pixel it belongs to, when their
- *     path has ended, 12 bytes of radiance per path in flight folded into the frame in the
+ *     path has ended, 12.25 bytes per path in flight (radiance, stored for the paths that met a
+ *     light, and a mask byte per pixel-iteration) folded into the frame in the
  *     reference's order afterwards, batches on two streams like PT_VARIANT_WAVEFRONT's.
  *     Everything else: PT_VARIANT_STEALING
  *   PT_VARIANT_STEALING: PT_VARIANT_REGENERATION, and a lane that has finished its pixel takes
