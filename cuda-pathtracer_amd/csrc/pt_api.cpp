@@ -795,7 +795,7 @@ static int wavefront_whole_paths(const pt_context *h)
     if (h->wf_dynamic_fetch <= 0 || h->accel != PT_ACCEL_AUTO || h->bvh.n_nodes == 0) return 0;
     if (h->wf_whole_paths >= 0) return h->wf_whole_paths;
     const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
-    if (h->memory_limit && h->memory_limit / (kWfQueueRecord + 3 * sizeof(float)) < paths_per_it) return 1;
+    if (h->memory_limit && h->memory_limit / (kWfQueueRecord + 3 * sizeof(float) + 1) < paths_per_it) return 1;
     return 2;
 }
 
@@ -817,13 +817,13 @@ static int wavefront_mode(const pt_context *h, uint32_t n_iterations)
     return wavefront_whole_paths(h);
 }
 
-// The path pool also keeps one mask byte per pixel-iteration (which of its four paths have an
+// Beside queues and radiance, one mask byte per pixel-iteration (which of its four paths have an
 // entry in the radiance buffer): a quarter of a byte per path, planned as one.
 static uint64_t wavefront_bytes_per_path(int mode)
 {
-    return (mode == 0 ? 2 : mode == 2 ? 1 : 0) * kWfQueueRecord + 3 * sizeof(float) + (mode == 3 ? 1 : 0);
+    return (mode == 0 ? 2 : mode == 2 ? 1 : 0) * kWfQueueRecord + 3 * sizeof(float) + 1;
 }
-static uint64_t wavefront_mask_bytes(int mode, uint64_t paths) { return mode == 3 ? (paths / 4 + 3) / 4 * 4 : 0; }
+static uint64_t wavefront_mask_bytes(int mode, uint64_t paths) { (void)mode; return (paths / 4 + 3) / 4 * 4; }
 static uint64_t wavefront_queues(int mode) { return mode == 0 ? 2 : mode == 2 ? 1 : 0; }
 
 // Iterations per wavefront batch of a frame with `paths_per_it` paths per iteration, within the
@@ -943,7 +943,7 @@ static void fill_wavefront(const pt_context *h, WavefrontParams &p)
 // the resolve -- after the resolve of the batch before (`after`, the other set's event, or null):
 // the frame buffer takes the batches' iterations in order.
 static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, int mode, size_t counts_bytes, int set, hipStream_t stream,
-                                  hipEvent_t after, bool record = true)
+                                  hipEvent_t after, bool record = true, bool zero_radiance = false)
 {
     const bool tiled = scene_streams(p.scene);
     pt_context::WfPipe &pipe = h->wf_pipe[set];
@@ -953,7 +953,7 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, int mode, s
     // the resolve kernel leaves the counters at zero for the set's next batch
     if (pipe.counts_dirty) PT_HIP(h, hipMemsetAsync(pipe.counts, 0, counts_bytes, stream));
     pipe.counts_dirty = true;
-    if (mode != 3) {   // the queue-fed kernels add to the path's entry bounce by bounce; the path pool stores it once
+    if (zero_radiance) {   // parity hook of the queue-fed kernels: the radiance buffer is read for every path
         const uint64_t batch_paths = (uint64_t)p.n_iterations * p.rect_w * p.rect_h * 4;
         PT_HIP(h, hipMemsetAsync(pipe.radiance, 0, batch_paths * 3 * sizeof(float), stream));
     }
@@ -1391,7 +1391,7 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
         p.ray_counter = d_cnt;
         p.hit_ids = d_hits; p.pixel_rgb = d_rgb;
         p.store_all_paths = 1;   // `radiance` is read for every path
-        rc = launch_wavefront_batch(h, p, mode, counts_bytes, 0, h->stream, nullptr);
+        rc = launch_wavefront_batch(h, p, mode, counts_bytes, 0, h->stream, nullptr, true, radiance && mode != 3);
         if (rc != PT_OK) goto cleanup;
         // the batch's per-path radiance buffer has the layout of `radiance`
         if (radiance) DBG_HIP(hipMemcpyAsync(radiance, h->wf_pipe[0].radiance, n_paths * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));

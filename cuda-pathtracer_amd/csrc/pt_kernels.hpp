@@ -145,8 +145,8 @@ hipError_t launch_render_nee(const RenderParams &p, uint32_t grid_x, uint32_t gr
 // ---- wavefront (path-compaction) variant ------------------------------------------------------
 // A batch holds n_iterations x width x height x 4 paths.  Every bounce is one kernel launch over
 // a compacted queue of live paths in device memory; the emission a path collects is added to its
-// entry of `path_radiance` (zeroed per batch) bounce by bounce, in the order the reference adds it
-// to L, and wf_resolve folds the entries into the frame buffer in the reference's order.
+// entry of `path_radiance` bounce by bounce, in the order the reference adds it to L, and
+// wf_resolve folds the entries into the frame buffer in the reference's order.
 constexpr uint32_t kWfSubQueues = 64;     // independent sub-queues (one compaction counter each)
 constexpr uint32_t kWfCountStride = 32;   // uint32 per counter: every counter on its own 128-B line
 
@@ -178,10 +178,11 @@ struct WavefrontParams {
     uint32_t *counts;           // [max_bounces + 2][kWfSubQueues][kWfCountStride]: word 0 = paths alive
                                 // in sub-queue q entering bounce k, word 1 = fetch cursor of the
                                 // dynamic-fetch kernel over those paths
-    float *path_radiance;       // [paths][3], zero when the batch starts.  The path pool needs no zeroed buffer:
-                                // it stores the entries of the paths that collected light and marks them in path_mask
-    uint32_t *path_mask;        // path pool: one byte per pixel-iteration of the batch, bit s = sub-sample s has an
-                                // entry in path_radiance; zero when the batch starts, left at zero by the resolve
+    float *path_radiance;       // [paths][3], never zeroed: a path that collects light has an entry (the queue-fed
+                                // kernels add to it bounce by bounce, the path pool stores it when the path
+                                // ends) and is marked in path_mask
+    uint32_t *path_mask;        // one byte per pixel-iteration of the batch, bit s = sub-sample s has an entry in
+                                // path_radiance; zero when the batch starts, left at zero by the resolve
     int store_all_paths;        // path pool, parity hook: black paths are stored and marked too
     // resolve
     int accum_mode, overwrite;

@@ -83,14 +83,25 @@ PT_DEV void record_hit(const WavefrontParams &p, uint32_t n_pix, uint32_t pix, u
     if (p.hit_ids) p.hit_ids[batch_path_index(p, n_pix, pix, it_sub) * (size_t)(p.max_bounces + 1) + bounce] = best;
 }
 
-// Adds the emission a bounce collected to the path's radiance and clears it.  The entry starts
-// at zero and takes the terms in bounce order, one launch (or one lane) after the other: the sum
-// ((0 + e1) + e2) + ... is the one Trace builds in L (pathtracer.cu:136).
+// Marks a path of the batch in the mask (byte path >> 2, bit path & 3: the path has an entry in
+// path_radiance); returns whether it was marked before.
+PT_DEV bool mark_path(const WavefrontParams &p, size_t path)
+{
+    const uint32_t bit = 1u << ((uint32_t)(path & 15u) >> 2 << 3 | (uint32_t)(path & 3u));
+    return (atomicOr(p.path_mask + (path >> 4), bit) & bit) != 0u;
+}
+
+// Adds the emission a bounce collected to the path's radiance and clears it.  The entry takes the
+// terms in bounce order, one launch (or one lane) after the other: the sum ((0 + e1) + e2) + ...
+// is the one Trace builds in L (pathtracer.cu:136).  The buffer is never zeroed: a path's first
+// term starts its entry and marks the path in the mask; one lane at a time works on a path.
 PT_DEV void bank_radiance(const WavefrontParams &p, uint32_t n_pix, uint32_t pix, uint32_t it_sub, V3 &L)
 {
     if (L.x != 0.f || L.y != 0.f || L.z != 0.f) {
-        float *pr = p.path_radiance + batch_path_index(p, n_pix, pix, it_sub) * 3;
-        pr[0] += L.x; pr[1] += L.y; pr[2] += L.z;
+        const size_t path = batch_path_index(p, n_pix, pix, it_sub);
+        float *pr = p.path_radiance + path * 3;
+        const V3 have = mark_path(p, path) ? mk(pr[0], pr[1], pr[2]) : mk(0.f, 0.f, 0.f);
+        pr[0] = have.x + L.x; pr[1] = have.y + L.y; pr[2] = have.z + L.z;
         L = mk(0.f, 0.f, 0.f);
     }
 }
@@ -496,8 +507,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontP
                     const size_t path = batch_path_index(p, n_pix, pix, it_sub);
                     float *pr = p.path_radiance + path * 3;
                     pr[0] = L.x; pr[1] = L.y; pr[2] = L.z;
-                    // byte (path >> 2) of the mask, bit (path & 3)
-                    atomicOr(p.path_mask + (path >> 4), 1u << ((uint32_t)(path & 15u) >> 2 << 3 | (uint32_t)(path & 3u)));
+                    (void)mark_path(p, path);
                 }
                 cont = !end;
                 has = cont;
@@ -524,19 +534,14 @@ __global__ __launch_bounds__(kBlockThreads) void wf_resolve_kernel(const Wavefro
             const size_t group = (size_t)k * n_pix + local;
             const float *pr = p.path_radiance + (group << 2) * 3;
             V3 c = mk(0.f, 0.f, 0.f);
-            if (p.path_pool) {
-                // only the marked sub-samples have an entry; the others were black (c + 0 == c)
-                unsigned char *mask = reinterpret_cast<unsigned char *>(p.path_mask) + group;
-                const uint32_t m = *mask;
-                if (m) {
-                    *mask = 0;   // for the buffer set's next batch
+            // only the marked sub-samples have an entry; the others were black (c + 0 == c)
+            unsigned char *mask = reinterpret_cast<unsigned char *>(p.path_mask) + group;
+            const uint32_t m = *mask;
+            if (m) {
+                *mask = 0;   // for the buffer set's next batch
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        if (m & (1u << s)) c = c + mk(pr[s * 3], pr[s * 3 + 1], pr[s * 3 + 2]);
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) c = c + mk(pr[s * 3], pr[s * 3 + 1], pr[s * 3 + 2]);
+                for (int s = 0; s < 4; ++s)
+                    if (m & (1u << s)) c = c + mk(pr[s * 3], pr[s * 3 + 1], pr[s * 3 + 2]);
             }
             acc = accumulate_pixel(acc, c, p.first_iteration + k, p.accum_mode, &cpix);
         }
