@@ -69,6 +69,29 @@ def test_image_matches_golden_bit_exact(pt, torch_cuda, name, variant):
     tr.Release()
 
 
+@pytest.mark.parametrize("variant", [-1, 100])
+def test_radiance_mask_is_left_clean_between_batches_and_rectangles(pt, torch_cuda, variant):
+    """The path pool and the queue-fed kernels store the radiance of the paths that met a light
+    only and mark them in a mask that the resolve clears; nothing zeroes the buffers between
+    batches.  Renders, parity-hook rectangles of another shape (which store every path) and
+    batches cut by a memory limit share one buffer set here: every image must stay the golden one,
+    and the per-path radiances of the hook must be the golden ones each time."""
+    g = load_golden("demo_64x48_d8_it1-4")
+    first, n = int(g["first_iteration"]), int(g["n_iterations"])
+    tr = make_tracer(pt, g, variant)
+    h, w = g["image"].shape[:2]
+    for limit in (0, 13 * w * h * 4 * 2 + 2**20, 0):          # 0: no limit; then batches of one iteration in two sets
+        tr.SetMemoryLimit(limit)
+        img = render(torch_cuda, tr, first, n).cpu().numpy()
+        assert img.tobytes() == g["image"].tobytes()
+        hits, rad, rgb, _ = tr.DebugTrace(3, 5, 3 + 17, 5 + 9, first)
+        assert np.array_equal(hits, g["hit_ids"][0][5:14, 3:20].astype(np.int32))
+        assert rad.tobytes() == np.ascontiguousarray(g["path_radiance"][0][5:14, 3:20].astype(np.float32)).tobytes()
+    img = render(torch_cuda, tr, first, n).cpu().numpy()
+    assert img.tobytes() == g["image"].tobytes()
+    tr.Release()
+
+
 # + 3: whole pixel-iterations change hands even in a one-iteration launch (the default there: single paths)
 @pytest.mark.parametrize("variant", SHIPPED_VARIANTS + [500 + 3, 100])
 @pytest.mark.parametrize("name", golden_names())
