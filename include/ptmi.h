@@ -177,7 +177,8 @@ int pt_reset_counters(pt_handle h);
  *   PT_VARIANT_CLASSIC: megakernel, a wave starts new paths only when all its lanes are idle
  *   PT_VARIANT_WAVEFRONT: one launch per bounce over compacted path queues in device memory
  *     (100 bytes per path in flight, or 56 / 12 for BVH scenes whose persistent waves follow whole
- *     paths, see PT_TUNE_WAVEFRONT_WHOLE_PATHS; up to about 6.7 GB, allocated on first use -- see
+ *     paths, see PT_TUNE_WAVEFRONT_WHOLE_PATHS, and a mask byte per four paths, planned as one per
+ *     path; up to about 6.7 GB, allocated on first use -- see
  *     pt_memory_footprint and pt_set_memory_limit).  A render of more iterations
  *     than fit runs as batches that alternate between two buffer sets on two streams (the
  *     caller's and one of the instance's), so that one batch's launches fill the chip while the
@@ -269,7 +270,8 @@ int pt_debug_build_bvh(const pt_sphere *spheres, uint32_t n_spheres, uint32_t co
                        int32_t *leaf_index, int32_t *big_index);
 /* Test hook, host only (no device needed): how a render of n_iterations over a width x height
  * frame is cut into batches by the path pool and the wavefront variant, with row bands
- * (band_world <= 1: none) and bytes_per_path of buffers per path in flight (12, 56 or 100) under
+ * (band_world <= 1: none) and bytes_per_path of buffers per path in flight (the library plans
+ * with 13, 57 or 101) under
  * memory_limit (0: the default budget).  out = {rows this rank owns, iterations per batch (0: not
  * one iteration fits), buffer sets (1 or 2; batches alternate between them), slots per
  * sub-queue}. */
