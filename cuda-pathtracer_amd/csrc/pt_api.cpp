@@ -82,7 +82,7 @@ struct pt_context {
     int last_launch;             // PT_LAUNCH_* of the last render
     uint32_t wf_sub_capacity;   // paths per sub-queue the buffers were sized for
     uint64_t wf_capacity;       // paths per batch the buffers were sized for
-    uint64_t wf_mask_bytes;     // size of the path pool's mask behind a set's counters (0: none)
+    uint64_t wf_mask_bytes;     // size of the radiance mask behind a set's counters
     std::string error;
 };
 
@@ -675,7 +675,7 @@ static uint64_t wavefront_sub_capacity(uint32_t w, uint32_t h, uint64_t iteratio
     return (blocks + kWfSubQueues - 1) / kWfSubQueues * 256;
 }
 static uint64_t wavefront_bytes_per_path(int mode);
-static uint64_t wavefront_mask_bytes(int mode, uint64_t paths);
+static uint64_t wavefront_mask_bytes(uint64_t paths);
 static uint64_t wavefront_queues(int mode);
 
 int pt_set_memory_limit(pt_handle h, uint64_t bytes)
@@ -710,7 +710,7 @@ int pt_memory_footprint(pt_handle h, uint32_t n_iterations, uint64_t bytes[2])
         const uint64_t sub_cap = wavefront_sub_capacity(h->camera.width, owned_rows(h), batch_it);
         const uint64_t n_queues = wavefront_queues(wf_mode);
         const uint64_t need = wf_sets * (n_queues * sub_cap * kWfSubQueues * queue_bytes + capacity * 3 * sizeof(float) + counts +
-                                         wavefront_mask_bytes(wf_mode, capacity));
+                                         wavefront_mask_bytes(capacity));
         if (need > wf_next) wf_next = need;
     } else if (n_iterations && h->scene_ready && !h->wavefront && h->steal && !h->steal_alloc_failed &&
                (!h->memory_limit || kStealPoolBytes + kStealMaskBytes <= h->memory_limit)) {
@@ -823,7 +823,7 @@ static uint64_t wavefront_bytes_per_path(int mode)
 {
     return (mode == 0 ? 2 : mode == 2 ? 1 : 0) * kWfQueueRecord + 3 * sizeof(float) + 1;
 }
-static uint64_t wavefront_mask_bytes(int mode, uint64_t paths) { (void)mode; return (paths / 4 + 3) / 4 * 4; }
+static uint64_t wavefront_mask_bytes(uint64_t paths) { return (paths / 4 + 3) / 4 * 4; }
 static uint64_t wavefront_queues(int mode) { return mode == 0 ? 2 : mode == 2 ? 1 : 0; }
 
 // Iterations per wavefront batch of a frame with `paths_per_it` paths per iteration, within the
@@ -881,10 +881,10 @@ int pt_debug_plan_batches(uint32_t width, uint32_t height, uint32_t band_rows, u
 static int ensure_wavefront(pt_context *h, int mode, uint64_t capacity, uint64_t sub_cap64, uint32_t sets, size_t *counts_bytes_out)
 {
     const int n_queues = (int)wavefront_queues(mode);
-    const uint64_t mask_bytes = wavefront_mask_bytes(mode, capacity);
+    const uint64_t mask_bytes = wavefront_mask_bytes(capacity);
     if (sub_cap64 > 0xffffff00ull) return fail(h, PT_ERR_INVALID, "wavefront variant: image too large");
     const uint32_t sub_cap = (uint32_t)sub_cap64;
-    // the counters, and behind them the path pool's mask: both zero between batches
+    // the counters, and behind them the radiance mask: both zero between batches
     const size_t counters_bytes = (size_t)(h->max_bounces + 2) * kWfSubQueues * kWfCountStride * sizeof(uint32_t);
     bool have = capacity <= h->wf_capacity && sub_cap <= h->wf_sub_capacity && h->wf_n_queues >= n_queues &&
                 mask_bytes <= h->wf_mask_bytes;
