@@ -495,6 +495,8 @@ __global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontP
         if (TILED || __any(has)) {
             float tmax;
             int best;
+            PT_LS(4);
+            if (has) PT_LS(17);
             intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, has, o, d, tmax, best);
             bool cont = false;
             if (has) {
