@@ -43,7 +43,7 @@ examples: examples/pt_headless tools/pt_bench
 tools/pt_bench: tools/pt_bench.cpp $(PKG)/libptmi.so
 	$(HIPCC) -O2 -std=c++17 -Iinclude -o $@ tools/pt_bench.cpp -L$(PKG) -lptmi -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
-examples/pt_headless: examples/main.cpp $(PKG)/host/pathtracer.hpp $(PKG)/host/multi_gpu.hpp $(PKG)/host/scene_file.hpp $(PKG)/libptmi.so
+examples/pt_headless: examples/main.cpp $(PKG)/host/pathtracer.hpp $(PKG)/host/multi_gpu.hpp $(PKG)/host/shard_plan.hpp $(PKG)/host/scene_file.hpp $(PKG)/libptmi.so
 	$(HIPCC) -O2 -std=c++17 -ffp-contract=off -Iinclude -I$(PKG)/host -o $@ examples/main.cpp \
 	    -L$(PKG) -lptmi -L/opt/rocm/lib -lrccl -lpthread -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
@@ -58,9 +58,9 @@ tools/asan/plain_oracle: tools/asan/asan_oracle.c oracle/pt_oracle.c oracle/pt_o
 tools/asan/asan_oracle: tools/asan/asan_oracle.c oracle/pt_oracle.c oracle/pt_oracle.h oracle/pt_oracle_math.h oracle/pt_oracle_nee.h
 	gcc -std=c11 $(SANFLAGS) -Wall -Wextra -Ioracle -o $@ tools/asan/asan_oracle.c oracle/pt_oracle.c -lm -lpthread
 tools/asan/asan_host: tools/asan/asan_host.cpp $(CSRC)/pt_bvh.cpp $(CSRC)/pt_scene.cpp $(CSRC)/pt_checkpoint.cpp \
-                      $(CSRC)/pt_bvh.hpp $(CSRC)/pt_checkpoint.hpp $(PKG)/host/scene_file.hpp $(PKG)/host/pathtracer.hpp include/ptmi.h
+                      $(CSRC)/pt_bvh.hpp $(CSRC)/pt_checkpoint.hpp $(PKG)/host/scene_file.hpp $(PKG)/host/pathtracer.hpp $(PKG)/host/shard_plan.hpp include/ptmi.h
 	g++ -std=c++17 $(SANFLAGS) -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -I$(CSRC) -I$(PKG)/host -o $@ \
-	    tools/asan/asan_host.cpp $(CSRC)/pt_bvh.cpp $(CSRC)/pt_scene.cpp $(CSRC)/pt_checkpoint.cpp
+	    tools/asan/asan_host.cpp $(CSRC)/pt_bvh.cpp $(CSRC)/pt_scene.cpp $(CSRC)/pt_checkpoint.cpp -lpthread
 
 clean:
 	rm -f $(PKG)/libptmi.so examples/pt_headless tools/asan/asan_oracle tools/asan/asan_host tools/asan/plain_oracle

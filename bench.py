@@ -311,7 +311,7 @@ def main():
     if tile_split:   # every rank renders all world x iterations iterations of its own bands
         first, n_it = 1, wl["iterations"] * world
     else:
-        first, n_it = sharding.sample_range(rank, world, wl["iterations"])
+        first, n_it = sharding.sample_range(rank, world, wl["iterations"] * world)
     total_iterations = wl["iterations"] * world
     step_no = [0]
 

@@ -80,6 +80,7 @@ ABI = [
     ("pt_accel_stats", _i32, [_vp, _pu64]),
     ("pt_lane_stats", _i32, [_vp, _pu64]),
     ("pt_debug_build_bvh", _i32, [_vp, _u32, _pu32, _vp, _vp, _vp]),
+    ("pt_debug_bvh_grid", _i32, [_vp, _u32, _vp, _vp, _u32]),
     ("pt_debug_plan_batches", _i32, [_u32, _u32, _u32, _u32, _u32, _u32, _u32, _u64, _pu32]),
     ("pt_last_kernel_ms", _i32, [_vp, _pf]),
     ("pt_last_launch", _i32, [_vp, ctypes.POINTER(ctypes.c_int)]),
@@ -248,7 +249,13 @@ def debug_build_bvh(spheres):
     leaf = np.zeros((counts[1], 4), np.int32)
     big = np.zeros(counts[2], np.int32)
     lib.pt_debug_build_bvh(_ptr(sph), len(sph), counts, _ptr(nodes), _ptr(leaf), _ptr(big))
-    return {"nodes": nodes, "leaf_index": leaf, "big_index": big, "depth": int(counts[3])}
+    # the 16-bit grid form the device reads: planes as origin + q * step
+    grid = np.zeros(6, np.float32)
+    qnodes = np.zeros((counts[0], 16), np.uint32)
+    if lib.pt_debug_bvh_grid(_ptr(sph), len(sph), _ptr(grid), _ptr(qnodes), counts[0]) != PT_OK:
+        raise ValueError("pt_debug_bvh_grid failed")
+    return {"nodes": nodes, "leaf_index": leaf, "big_index": big, "depth": int(counts[3]),
+            "grid_origin": grid[:3], "grid_step": grid[3:], "qnodes": qnodes}
 
 
 class Pathtracer:

@@ -548,6 +548,23 @@ int pt_debug_build_bvh(const pt_sphere *spheres, uint32_t n_spheres, uint32_t co
     return PT_OK;
 }
 
+int pt_debug_bvh_grid(const pt_sphere *spheres, uint32_t n_spheres, float grid[6], uint32_t *qnodes, uint32_t n_nodes)
+{
+    if (!grid || !qnodes || (n_spheres && !spheres)) return PT_ERR_INVALID;
+    std::vector<float4> sph(n_spheres);
+    std::vector<float> radius(n_spheres);
+    for (uint32_t i = 0; i < n_spheres; ++i) {
+        sph[i] = make_float4(spheres[i].pos[0], spheres[i].pos[1], spheres[i].pos[2], spheres[i].radius * spheres[i].radius);
+        radius[i] = spheres[i].radius;
+    }
+    BvhData d;
+    if (!build_bvh(sph.data(), radius.data(), n_spheres, &d)) return PT_ERR_STATE;
+    if (d.qnodes.size() != (size_t)n_nodes * 4) return PT_ERR_INVALID;
+    for (int a = 0; a < 3; ++a) { grid[a] = d.grid_origin[a]; grid[3 + a] = d.grid_step[a]; }
+    memcpy(qnodes, d.qnodes.data(), d.qnodes.size() * sizeof(uint4));
+    return PT_OK;
+}
+
 int pt_set_accel_budget(pt_handle h, uint32_t visits)
 {
     if (!h) return PT_ERR_INVALID;
@@ -799,6 +816,20 @@ static int wavefront_whole_paths(const pt_context *h)
     return 2;
 }
 
+// The pool and wavefront kernels turn path numbers into rows, bands and iterations with a division
+// through the float reciprocal (div_small in pt_wavefront.hip), exact while every quotient stays
+// below 2^20 and every divisor below 2^30: rows of the frame, iterations of a batch (capped in
+// plan_batches), band_rows * world.  Frames outside that go through the megakernel.
+static bool wavefront_indexing_ok(uint32_t height, uint32_t band_rows, uint32_t band_world)
+{
+    if (height >= (1u << 20)) return false;
+    return band_world <= 1 || (uint64_t)band_rows * band_world < (1ull << 30);
+}
+static bool wavefront_indexing_ok(const pt_context *h)
+{
+    return wavefront_indexing_ok(h->camera.height, h->band_rows, h->band_world);
+}
+
 // Launches over a scene that is rendered by the linear scan (resident in LDS or streamed through
 // it in tiles): the path pool (wf_pool_kernel) instead of the megakernel, whose lanes own pixels.
 static bool takes_pool(const pt_context *h, uint64_t last_iteration, uint32_t n_iterations)
@@ -807,7 +838,7 @@ static bool takes_pool(const pt_context *h, uint64_t last_iteration, uint32_t n_
     fill_scene(h, s);
     return h->auto_variant && h->integrator == PT_INTEGRATOR_PATH && s.bvh.n_nodes == 0 &&
            n_iterations > 0 && n_iterations <= (uint32_t)h->pool_max_iterations &&
-           last_iteration < (1u << 30);
+           last_iteration < (1u << 30) && wavefront_indexing_ok(h);
 }
 
 // How a render of n_iterations maps to launches: 0..2 as wavefront_whole_paths, 3: the path pool.
@@ -843,8 +874,10 @@ static uint32_t plan_batches(uint64_t paths_per_it, uint32_t n_iterations, uint6
         if (batch_it < 1) batch_it = memory_limit ? 0 : 1;
     }
     if (batch_it > n_iterations) batch_it = n_iterations;
-    // the kernels number the paths of a batch with 32 bits
+    // the kernels number the paths of a batch with 32 bits, and find a path's iteration within the
+    // batch by a division that is exact for quotients below 2^20
     if (batch_it > 0xffffffffull / paths_per_it) batch_it = 0xffffffffull / paths_per_it;
+    if (batch_it > (1u << 20) - 1) batch_it = (1u << 20) - 1;
     if (sets) *sets = n_sets;
     return (uint32_t)batch_it;
 }
@@ -867,7 +900,8 @@ int pt_debug_plan_batches(uint32_t width, uint32_t height, uint32_t band_rows, u
     const uint32_t rows = owned_rows(height, band_rows, band_rank, band_world);
     const uint64_t paths_per_it = (uint64_t)width * rows * 4;
     uint32_t sets = 1;
-    const uint32_t batch_it = paths_per_it && n_iterations ? plan_batches(paths_per_it, n_iterations, bytes_per_path, memory_limit, 0, &sets) : 0;
+    const uint32_t batch_it = paths_per_it && n_iterations && wavefront_indexing_ok(height, band_rows, band_world)
+                                  ? plan_batches(paths_per_it, n_iterations, bytes_per_path, memory_limit, 0, &sets) : 0;
     out[0] = rows;
     out[1] = batch_it;
     out[2] = batch_it ? sets : 0;
@@ -1062,7 +1096,7 @@ static bool takes_wavefront(const pt_context *h, uint64_t last_iteration, uint32
     if (h->wavefront) return true;
     if (takes_pool(h, last_iteration, n_iterations)) return true;
     return h->auto_variant && h->accel == PT_ACCEL_AUTO && h->bvh.n_nodes > 0 &&
-           h->integrator == PT_INTEGRATOR_PATH && last_iteration < (1u << 30);
+           h->integrator == PT_INTEGRATOR_PATH && last_iteration < (1u << 30) && wavefront_indexing_ok(h);
 }
 
 // The handle's own scratch of the work-stealing megakernel (pool + occupancy bits in one
@@ -1121,8 +1155,12 @@ static int setup_steal(pt_context *h, RenderParams &p, uint32_t grid_x, uint32_t
         sc.tickets = h->d_tickets;
         sc.ticket_words = (uint32_t)h->tickets_capacity;
     }
-    if (fixed)   // contents of the last call: the bits must start at zero, and so must the tickets
-        PT_HIP(h, hipMemsetAsync(sc.mask, 0, kStealMaskBytes + (n_chunks > 1 ? words * sizeof(uint32_t) : 0), h->stream));
+    // The static array is shared by every handle and stream of the process on this device.  Its
+    // occupancy bits are zero when the library is loaded and every workgroup returns the block it took,
+    // so they are never cleared here: clearing them under another stream's launch in flight would hand
+    // its blocks out a second time.  The tickets hold the last call's counts and must start at zero.
+    if (fixed && n_chunks > 1)
+        PT_HIP(h, hipMemsetAsync(sc.tickets, 0, words * sizeof(uint32_t), h->stream));
     if (n_chunks > 1 && sc.tickets && words <= sc.ticket_words) {
         if (!fixed) PT_HIP(h, hipMemsetAsync(sc.tickets, 0, words * sizeof(uint32_t), h->stream));
         p.n_chunks = n_chunks;
@@ -1187,6 +1225,8 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
     if (h->iteration > 0xffffffffu - n_iterations) return fail(h, PT_ERR_INVALID, "iteration counter overflow");
     if (h->wavefront && h->integrator != PT_INTEGRATOR_PATH)
         return fail(h, PT_ERR_STATE, "the wavefront variant only implements PT_INTEGRATOR_PATH");
+    if (h->wavefront && !wavefront_indexing_ok(h))
+        return fail(h, PT_ERR_INVALID, "the wavefront variant takes frames of fewer than 2^20 rows and band_rows * world below 2^30");
     if (takes_wavefront(h, h->iteration + (uint64_t)n_iterations, n_iterations)) {
         const int rc = enqueue_wavefront(h, dbuf, n_iterations);
         // PT_VARIANT_AUTO: when the queues cannot be had the megakernel renders the same image
@@ -1375,7 +1415,8 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
     DBG_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
     // The rectangle goes through the kernels a render of this instance would use: the per-bounce
     // wavefront launches, the work-stealing megakernel, or the plain one.
-    if (takes_wavefront(h, iteration, 1) && h->integrator == PT_INTEGRATOR_PATH && iteration < (1u << 30)) {
+    if (takes_wavefront(h, iteration, 1) && h->integrator == PT_INTEGRATOR_PATH && iteration < (1u << 30) &&
+        wavefront_indexing_ok(h)) {
         const int mode = wavefront_mode(h, 1);
         size_t counts_bytes = 0;
         rc = ensure_wavefront(h, mode, n_paths, wavefront_sub_capacity(x1 - x0, y1 - y0, 1), 1, &counts_bytes);

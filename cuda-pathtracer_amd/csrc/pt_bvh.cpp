@@ -205,16 +205,22 @@ struct Builder {
 
 } // namespace
 
-// The 16-bit grid form of the nodes (layout: pt_bvh.hpp).  lo / hi: extent of the bounded spheres.
-static void quantize_nodes(BvhData *out, const float lo[3], const float hi[3])
+// The 16-bit grid form of the nodes (layout: pt_bvh.hpp).  lo / hi: extent of the bounded spheres;
+// box_slack: by how much a node box may exceed that extent on either side (the builder's slack on
+// every radius).  Returns false when a plane of a used box falls off the grid, whose clamped
+// coordinate would make the box tighter than the traversal's error bound assumes: the scene is
+// then rendered by the linear scan.
+static bool quantize_nodes(BvhData *out, const float lo[3], const float hi[3], double box_slack)
 {
     const size_t n_nodes = out->nodes.size() / kBvhNodeVec4;
     double origin[3], step[3];
     for (int a = 0; a < 3; ++a) {
         // the node boxes exceed the spheres' extent by their slack: leave a margin of 1/64 of the
-        // extent (and at least a little) on both sides, and four grid steps for the outward rounding
+        // extent on both sides -- or the slack itself where that is more, as on the short axis of a
+        // flat or elongated cloud, whose slack follows the cloud's diagonal -- and a little, and
+        // four grid steps for the outward rounding
         const double extent = std::max((double)hi[a] - (double)lo[a], 1e-3);
-        const double margin = extent / 64 + 1e-3;
+        const double margin = std::max(extent / 64, box_slack) + 1e-3;
         step[a] = (extent + 2 * margin) / 65520.0;
         out->grid_step[a] = (float)step[a];
         step[a] = (double)out->grid_step[a];                      // the step the device uses
@@ -222,6 +228,7 @@ static void quantize_nodes(BvhData *out, const float lo[3], const float hi[3])
         origin[a] = (double)out->grid_origin[a];
     }
     out->qnodes.assign(n_nodes * 4, make_uint4(0u, 0u, 0u, 0u));
+    bool on_grid = true;
     for (size_t k = 0; k < n_nodes; ++k) {
         const float4 *N = &out->nodes[k * kBvhNodeVec4];
         uint32_t q[6][4];
@@ -231,6 +238,7 @@ static void quantize_nodes(BvhData *out, const float lo[3], const float hi[3])
             for (int c = 0; c < 4; ++c) {
                 double g = ((double)v[c] - origin[a]) / step[a];
                 g = plane < 3 ? std::floor(g) - 2 : std::ceil(g) + 2;
+                if (g < 0 || g > 65535) on_grid = false;           // a used slot's plane (NaN compares false)
                 if (!(g >= 0)) g = 0;                              // NaN (unused slot) as well
                 if (g > 65535) g = 65535;
                 q[plane][c] = (uint32_t)g;
@@ -245,6 +253,7 @@ static void quantize_nodes(BvhData *out, const float lo[3], const float hi[3])
         memcpy(r, &N[6], 16);
         Q[3] = make_uint4(r[0], r[1], r[2], r[3]);
     }
+    return on_grid;
 }
 
 bool build_bvh(const float4 *sph, const float *radius, uint32_t n, BvhData *out)
@@ -308,7 +317,10 @@ bool build_bvh(const float4 *sph, const float *radius, uint32_t n, BvhData *out)
     const Subtree root = b.build(0, b.items.size());   // more than one leaf: the root is an inner node
     out->nodes.resize(kBvhNodeVec4);                   // wide node 0
     out->depth = b.emit_wide(root.ref, 0);
-    quantize_nodes(out, lo, hi);
+    // by how much an item's box radius exceeds the sphere's: (r + slack) * (1 + 1e-6) - r
+    double box_slack = 0;
+    for (const Item &it : b.items) box_slack = std::max(box_slack, (double)it.R - (double)radius[it.index]);
+    if (!quantize_nodes(out, lo, hi, box_slack)) return false;
     return out->depth <= kBvhMaxDepth;
 }
 

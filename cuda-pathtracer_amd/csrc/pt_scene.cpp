@@ -255,31 +255,12 @@ int pt_camera_rotate(pt_camera_state *cam, const float theta[3])
 int pt_camera_init(pt_camera_pod *out, const float eye[3], const float look_at[3],
                    const float up_[3], uint32_t width, uint32_t height, float fov)
 {
-    if (!out || !eye || !look_at || !up_ || width == 0 || height == 0) return PT_ERR_INVALID;
-    // Camera::Camera, camera.h:31-57
-    const float aspect = (float)height / (float)width;
-    const float hfov = fov;
-    const float vfov = hfov * aspect; // degrees scaled linearly, camera.h:36
-    const H3 e = h3(eye[0], eye[1], eye[2]), up = h3(up_[0], up_[1], up_[2]);
-    const H3 lookAt = h3(look_at[0], look_at[1], look_at[2]) - e;
-    const float dist = hlength(lookAt);
-    const H3 w = hdiv(lookAt, dist);
-    const H3 v = hnormalize(up - w * hdot(up, w));
-    const H3 u = hnormalize(hcross(w, v));
-    // Camera::UpdateParameter, camera.h:144-158; Radians, globals.h:95-97
-    const float m_pi = 3.14159265358979323846f;
-    float magnitude = dist * 2.f * tanf((m_pi / 180.f) * (hfov * 0.5f)) / (float)width;
-    const H3 pxX = u * magnitude;
-    magnitude = dist * 2.f * tanf((m_pi / 180.f) * (vfov * 0.5f)) / (float)height;
-    const H3 pxY = v * magnitude;
-    const H3 offset = pxY * (float)((float)height * 0.5f) - pxX * (float)((float)width * 0.5f);
-    const H3 first = w * dist + offset;
-    out->pos[0] = e.x; out->pos[1] = e.y; out->pos[2] = e.z;
-    out->px_x[0] = pxX.x; out->px_x[1] = pxX.y; out->px_x[2] = pxX.z;
-    out->px_y[0] = pxY.x; out->px_y[1] = pxY.y; out->px_y[2] = pxY.z;
-    out->first_ray_dir[0] = first.x; out->first_ray_dir[1] = first.y; out->first_ray_dir[2] = first.z;
-    out->width = width; out->height = height;
-    return PT_OK;
+    // Camera::Camera + UpdateParameter (camera.h:31-57,144-158): the POD of the full camera state
+    if (!out) return PT_ERR_INVALID;
+    pt_camera_state state;
+    const int rc = pt_camera_state_init(&state, eye, look_at, up_, width, height, fov);
+    if (rc == PT_OK) *out = state.pod;
+    return rc;
 }
 
 int pt_scene_build(int scene_id, uint64_t seed,

@@ -16,45 +16,19 @@
 #pragma once
 
 #include "pathtracer.hpp"
+#include "shard_plan.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <atomic>
+#include <mutex>
 #include <chrono>
+#include <memory>
 #include <string>
 #include <thread>
 #include <utility>
 #include <vector>
-
-enum class SplitMode { Tile, Sample };
-
-// What one device renders.
-struct ShardPlan {
-    uint32_t first_iteration = 1;   // 1-based, globally numbered
-    uint32_t n_iterations = 0;
-    uint32_t band_rows = 16;        // tile split: bands of this many rows, band b -> device b % world
-    std::vector<std::pair<uint32_t, uint32_t>> rows;   // [y0, y1) ranges this device renders
-};
-
-// Partition arithmetic (host only).  Sample split: iterations are dealt out in contiguous blocks,
-// the first (iterations % world) devices get one more.  Tile split: 16-row bands, round robin.
-inline ShardPlan MakeShardPlan(SplitMode split, uint32_t rank, uint32_t world, uint32_t iterations, uint32_t height)
-{
-    ShardPlan p;
-    if (split == SplitMode::Sample) {
-        const uint32_t base = iterations / world, extra = iterations % world;
-        p.n_iterations = base + (rank < extra ? 1u : 0u);
-        p.first_iteration = rank * base + (rank < extra ? rank : extra) + 1;
-        p.rows.emplace_back(0u, height);
-    } else {
-        p.n_iterations = iterations;
-        const uint32_t n_bands = (height + p.band_rows - 1) / p.band_rows;
-        for (uint32_t b = rank; b < n_bands; b += world)
-            p.rows.emplace_back(b * p.band_rows, (b + 1) * p.band_rows < height ? (b + 1) * p.band_rows : height);
-    }
-    return p;
-}
 
 struct MultiGpuResult {
     bool ok = false;
@@ -66,9 +40,18 @@ struct MultiGpuResult {
 
 // Renders `iterations` iterations of the scene on devices 0..world-1 and returns the mean image.
 // batch: iterations per launch on each device.
+//
+// A worker runs in two phases.  Phase 1 is everything that can fail on one device alone: stream,
+// buffer, scene upload, the render launches and a synchronisation that surfaces their errors.  The
+// workers then meet (ShardRendezvous): if any of them failed, none enters the collective and the
+// first error is returned.  Phase 2 is the one ncclReduce; should it fail on a device after the
+// others have entered it, every communicator is aborted (ncclCommAbort) so that the peers'
+// hipStreamSynchronize returns instead of waiting for the missing rank.
+// inject_failure_rank: that device reports a failure at the end of phase 1 (tests of the error path).
 inline MultiGpuResult RenderMultiGpu(const Camera &camera, int bounces, uint64_t seed, const std::vector<Material> &mv,
                                      const std::vector<Primitive> &pv, const std::vector<Light> &lv, int accel,
-                                     uint32_t world, SplitMode split, uint32_t iterations, uint32_t batch)
+                                     uint32_t world, SplitMode split, uint32_t iterations, uint32_t batch,
+                                     int inject_failure_rank = -1)
 {
     MultiGpuResult res;
     int n_dev = 0;
@@ -87,43 +70,74 @@ inline MultiGpuResult RenderMultiGpu(const Camera &camera, int bounces, uint64_t
     std::vector<uint64_t> rays(world, 0);
     std::vector<float *> buffers(world, nullptr);
     std::vector<hipStream_t> streams(world, nullptr);
-    std::atomic<int> ready{0};
+    ShardRendezvous rendezvous(world);
+    std::atomic<bool> aborted{false};
+    std::mutex abort_mutex;
+    // a collective that cannot complete: abort every communicator, once, so that no peer stays blocked in it
+    auto abort_all = [&]() {
+        std::lock_guard<std::mutex> lock(abort_mutex);
+        if (aborted.exchange(true)) return;
+        for (uint32_t r = 0; r < world; ++r) (void)ncclCommAbort(comms[r]);
+    };
     res.image.assign(n, 0.f);
     const auto t0 = std::chrono::steady_clock::now();
 
     auto worker = [&](uint32_t rank) {
         std::string &err = errors[rank];
+        Camera cam = camera;
+        std::unique_ptr<Pathtracer> pt;
+        // ---- phase 1: set-up and render, this device alone ----
         try {
-            if (hipSetDevice((int)rank) != hipSuccess) { err = "hipSetDevice failed"; return; }
-            if (hipStreamCreate(&streams[rank]) != hipSuccess) { err = "hipStreamCreate failed"; return; }
-            if (hipMalloc((void **)&buffers[rank], n * sizeof(float)) != hipSuccess) { err = "hipMalloc failed"; return; }
+            if (hipSetDevice((int)rank) != hipSuccess) err = "hipSetDevice failed";
+            else if (hipStreamCreate(&streams[rank]) != hipSuccess) err = "hipStreamCreate failed";
+            else if (hipMalloc((void **)&buffers[rank], n * sizeof(float)) != hipSuccess) err = "hipMalloc failed";
             // pixels this device does not own must be zero for the sum
-            if (hipMemsetAsync(buffers[rank], 0, n * sizeof(float), streams[rank]) != hipSuccess) { err = "hipMemsetAsync failed"; return; }
-            Camera cam = camera;
-            Pathtracer pt(&cam, bounces, seed);
-            if (!pt.Init(mv, pv, lv)) { err = pt.LastError(); return; }
-            pt.SetAccel(accel);
-            pt.SetStream(streams[rank]);
-            const ShardPlan plan = MakeShardPlan(split, rank, world, iterations, camera.Height());
-            if (split == SplitMode::Sample) pt.SetAccumMode(PT_ACCUM_SUM);
-            else pt.SetRowBands(plan.band_rows, rank, world);
-            pt.Reset();
-            pt.SetIteration(plan.first_iteration - 1);
-            for (uint32_t done = 0; done < plan.n_iterations;) {
-                const uint32_t k = plan.n_iterations - done < batch ? plan.n_iterations - done : batch;
-                pt.RunN(buffers[rank], k, /*sync=*/false);
-                done += k;
+            else if (hipMemsetAsync(buffers[rank], 0, n * sizeof(float), streams[rank]) != hipSuccess) err = "hipMemsetAsync failed";
+            else {
+                pt.reset(new Pathtracer(&cam, bounces, seed));
+                if (!pt->Init(mv, pv, lv)) err = pt->LastError();
             }
-            // one collective ends the render: sum of the accumulation buffers into device 0
-            const ncclResult_t r = ncclReduce(buffers[rank], buffers[rank], n, ncclFloat, ncclSum, 0, comms[rank], streams[rank]);
-            if (r != ncclSuccess) { err = std::string("ncclReduce: ") + ncclGetErrorString(r); return; }
-            if (hipStreamSynchronize(streams[rank]) != hipSuccess) { err = "hipStreamSynchronize failed"; return; }
-            rays[rank] = pt.RayCount();
-            if (rank == 0 && hipMemcpy(res.image.data(), buffers[0], n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
-                err = "hipMemcpy of the image failed";
-            pt.Release();
+            if (err.empty()) {
+                pt->SetAccel(accel);
+                pt->SetStream(streams[rank]);
+                const ShardPlan plan = MakeShardPlan(split, rank, world, iterations, camera.Height());
+                if (split == SplitMode::Sample) pt->SetAccumMode(PT_ACCUM_SUM);
+                else pt->SetRowBands(plan.band_rows, rank, world);
+                pt->Reset();
+                pt->SetIteration(plan.first_iteration - 1);
+                for (uint32_t done = 0; done < plan.n_iterations;) {
+                    const uint32_t k = plan.n_iterations - done < batch ? plan.n_iterations - done : batch;
+                    pt->RunN(buffers[rank], k, /*sync=*/false);
+                    done += k;
+                }
+                if (hipStreamSynchronize(streams[rank]) != hipSuccess) err = "hipStreamSynchronize after the render failed";
+            }
+            if (err.empty() && (int)rank == inject_failure_rank) err = "injected failure before the reduce";
         } catch (const std::exception &e) {
             err = e.what();
+        }
+        // ---- all devices meet: the collective is entered by everyone or by no one ----
+        const bool everyone_ok = rendezvous.Arrive(err.empty());
+        // ---- phase 2: one collective ends the render: sum of the accumulation buffers into device 0 ----
+        if (everyone_ok) {
+            const ncclResult_t r = ncclReduce(buffers[rank], buffers[rank], n, ncclFloat, ncclSum, 0, comms[rank], streams[rank]);
+            if (r != ncclSuccess) { err = std::string("ncclReduce: ") + ncclGetErrorString(r); abort_all(); }
+            else if (hipStreamSynchronize(streams[rank]) != hipSuccess) {
+                err = aborted.load() ? "reduce aborted after a failure on another device" : "hipStreamSynchronize after the reduce failed";
+                abort_all();
+            } else {
+                try {
+                    rays[rank] = pt->RayCount();
+                } catch (const std::exception &e) {
+                    err = e.what();
+                }
+                if (rank == 0 && hipMemcpy(res.image.data(), buffers[0], n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+                    err = "hipMemcpy of the image failed";
+            }
+        }
+        try {
+            if (pt) pt->Release();
+        } catch (const std::exception &) {
         }
     };
     std::vector<std::thread> threads;
@@ -135,7 +149,7 @@ inline MultiGpuResult RenderMultiGpu(const Camera &camera, int bounces, uint64_t
         (void)hipSetDevice((int)r);
         if (buffers[r]) (void)hipFree(buffers[r]);
         if (streams[r]) (void)hipStreamDestroy(streams[r]);
-        (void)ncclCommDestroy(comms[r]);
+        if (!aborted.load()) (void)ncclCommDestroy(comms[r]);   // ncclCommAbort has freed an aborted communicator
         if (!errors[r].empty() && res.error.empty()) res.error = "device " + std::to_string(r) + ": " + errors[r];
         res.rays += rays[r];
     }

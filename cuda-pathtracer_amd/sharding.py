@@ -4,8 +4,9 @@ Every (pixel, iteration, sub-sample) is independent given the counter-based RNG,
 shards without any exchange during rendering; the only collective is ONE sum of the
 accumulation buffers at the end (width*height*3 floats: 24.9 MB at 1080p, 99.5 MB at 4K).
 
-* sample-range split: rank r renders iterations [r*n+1, (r+1)*n] into a SUM buffer; after the
-  reduce the root scales by 1/(world*n).  fp32 summation order differs from the sequential
+* sample-range split: the render's iterations are dealt out in contiguous blocks (the first
+  `iterations % world` ranks get one more), each rank renders its block into a SUM buffer; after
+  the reduce the root scales by 1/iterations.  fp32 summation order differs from the sequential
   running mean, so the result matches a 1-GPU render to rounding (not bit for bit).
 * tile split: the image is cut into row bands, band b belongs to rank b % world; ranks leave
   foreign pixels at zero, so the same sum reproduces the 1-GPU image bit for bit (x + 0 == x).
@@ -18,11 +19,15 @@ from __future__ import annotations
 from typing import Callable, Tuple
 
 
-def sample_range(rank: int, world: int, iterations_per_rank: int) -> Tuple[int, int]:
-    """(first_iteration, n_iterations) of `rank`; iterations are 1-based and globally numbered."""
-    if not (0 <= rank < world) or iterations_per_rank < 0:
+def sample_range(rank: int, world: int, iterations: int) -> Tuple[int, int]:
+    """(first_iteration, n_iterations) of `rank` out of a render of `iterations` iterations in
+    total; iterations are 1-based and globally numbered.  Contiguous blocks, the first
+    `iterations % world` ranks get one more (the arithmetic of MakeShardPlan in
+    host/multi_gpu.hpp); a rank may get none."""
+    if not (0 <= rank < world) or iterations < 0:
         raise ValueError("bad rank/world/iterations")
-    return rank * iterations_per_rank + 1, iterations_per_rank
+    base, extra = divmod(iterations, world)
+    return rank * base + min(rank, extra) + 1, base + (1 if rank < extra else 0)
 
 
 def owned_bands(height: int, band_rows: int, rank: int, world: int):
@@ -47,17 +52,18 @@ def reduce_to_root(buffer, dist=None, dst: int = 0, async_op: bool = False, sing
     return work if async_op else buffer
 
 
-def render_sample_split(render_sum: Callable, rank: int, world: int, iterations_per_rank: int,
+def render_sample_split(render_sum: Callable, rank: int, world: int, iterations: int,
                         dist=None, dst: int = 0):
-    """render_sum(first_iteration, n_iterations) -> tensor holding the SUM over that range.
+    """render_sum(first_iteration, n_iterations) -> tensor holding the SUM over that range (all
+    zero for an empty range).
 
-    Returns the mean image over world*iterations_per_rank iterations on rank `dst` (other ranks
-    get their partial sums back)."""
-    first, n = sample_range(rank, world, iterations_per_rank)
+    Returns the mean image over `iterations` iterations (the whole render's, any split over the
+    ranks) on rank `dst` (other ranks get their partial sums back)."""
+    first, n = sample_range(rank, world, iterations)
     buf = render_sum(first, n)
     reduce_to_root(buf, dist, dst)
     if rank == dst:
-        buf.mul_(1.0 / float(world * iterations_per_rank))
+        buf.mul_(1.0 / float(iterations))
     return buf
 
 

@@ -22,6 +22,8 @@
 // --split S        tile: 16-row bands dealt round robin, bit-identical to one GPU (default);
 //                  sample: contiguous blocks of iterations, summed and scaled
 // --plan           print which rows and iterations each device would render and exit (no GPU)
+// --inject-failure R   (tests) device R of a sharded render reports a failure before the closing
+//                  reduce: the render must end with that error, no device may wait in the collective
 #include "multi_gpu.hpp"
 #include "pathtracer.hpp"
 #include "scene_file.hpp"
@@ -85,6 +87,7 @@ int main(int argc, char **argv)
     int accel = PT_ACCEL_AUTO;
     bool dump = false, plan_only = false, split_given = false;
     uint32_t gpus = 1;
+    int inject_failure = -1;
     SplitMode split = SplitMode::Tile;
     std::string scene = "demo", out = "pt_headless.ppm", checkpoint, resume;
 
@@ -118,6 +121,7 @@ int main(int argc, char **argv)
             split_given = true;
         }
         else if (a == "--gpus") { if (!number(1, 64, &x)) return usage("bad --gpus"); gpus = (uint32_t)x; }
+        else if (a == "--inject-failure") { if (!number(0, 63, &x)) return usage("bad --inject-failure"); inject_failure = (int)x; }
         else if (a == "--width") { if (!number(1, 65536, &x)) return usage("bad --width"); width = (uint32_t)x; }
         else if (a == "--height") { if (!number(1, 65536, &x)) return usage("bad --height"); height = (uint32_t)x; }
         else if (a == "--iterations") { if (!number(0, 1u << 30, &x)) return usage("bad --iterations"); iterations = (uint32_t)x; }
@@ -155,7 +159,7 @@ int main(int argc, char **argv)
         try {
             Camera camera(sd.eye, sd.look_at, sd.up, width, height, 0.f, 0.f, sd.fov);
             const MultiGpuResult r = RenderMultiGpu(camera, bounces, seed, sd.materials, sd.primitives, sd.lights, accel,
-                                                    gpus, split, iterations, batch);
+                                                    gpus, split, iterations, batch, inject_failure);
             if (!r.ok) { fprintf(stderr, "ERROR: %s\n", r.error.c_str()); return 1; }
             printf("Pathtracer (%.4f sps : %u) on %u GPU(s), %s split, %.3f G bounces/s\n", iterations / r.seconds, iterations,
                    gpus, split == SplitMode::Tile ? "tile" : "sample", (double)r.rays / r.seconds / 1e9);

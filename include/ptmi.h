@@ -268,6 +268,12 @@ int pt_set_accel_budget(pt_handle h, uint32_t visits);
  * [always-tested].  Call once to size, once to fill. */
 int pt_debug_build_bvh(const pt_sphere *spheres, uint32_t n_spheres, uint32_t counts[4], float *nodes,
                        int32_t *leaf_index, int32_t *big_index);
+/* Test hook, host only: the 16-bit grid form of the same nodes, which is what the device reads.
+ * grid = {origin x, y, z, step x, y, z} (plane = origin + q * step); qnodes [n_nodes][16] words of a
+ * node with n_nodes = counts[0] of pt_debug_build_bvh: words 0..11 hold the planes lo.x, lo.y, lo.z,
+ * hi.x, hi.y, hi.z, two words each (children 0|1 and 2|3, the lower child in the low half), words
+ * 12..15 the four child references.  PT_ERR_STATE when no hierarchy is built for these spheres. */
+int pt_debug_bvh_grid(const pt_sphere *spheres, uint32_t n_spheres, float grid[6], uint32_t *qnodes, uint32_t n_nodes);
 /* Test hook, host only (no device needed): how a render of n_iterations over a width x height
  * frame is cut into batches by the path pool and the wavefront variant, with row bands
  * (band_world <= 1: none) and bytes_per_path of buffers per path in flight (the library plans

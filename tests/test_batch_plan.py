@@ -53,3 +53,18 @@ def test_rejects_nonsense(pt):
     with pytest.raises(ValueError):
         pt.debug_plan_batches(10, 10, 1, 12, bands=(16, 3, 3))
     assert pt.debug_plan_batches(10, 10, 0, 12)[1:3] == (0, 0)
+
+
+def test_frames_outside_the_index_arithmetic_are_not_planned(pt):
+    """The pool and wavefront kernels divide path numbers through a float reciprocal, exact for
+    quotients below 2^20 (rows, iterations of a batch) and divisors below 2^30 (band_rows * world):
+    taller frames and wider band periods are not given to them (batch 0: the megakernel renders),
+    and no batch holds 2^20 iterations or more."""
+    assert pt.debug_plan_batches(16, (1 << 20) - 1, 1, 12)[1:3] == (1, 1)
+    assert pt.debug_plan_batches(16, 1 << 20, 1, 12)[1:3] == (0, 0)
+    assert pt.debug_plan_batches(1, 5_000_000, 4, 12)[1:3] == (0, 0)
+    assert pt.debug_plan_batches(64, 1080, 4, 12, bands=(16, 0, (1 << 26) - 1))[1] > 0
+    assert pt.debug_plan_batches(64, 1080, 4, 12, bands=(16, 0, 1 << 26))[1:3] == (0, 0)
+    # a tiny frame and millions of iterations: the memory would hold them all, the division would not
+    rows, batch, sets, _ = pt.debug_plan_batches(2, 2, 1 << 24, 12)
+    assert rows == 2 and 1 <= batch < (1 << 20) and sets in (1, 2)

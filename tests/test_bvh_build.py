@@ -63,6 +63,20 @@ def check(pt, sph):
 
     _, _, depth = walk(0, 0)
     assert depth == b["depth"] <= 28
+
+    # The 16-bit grid form the device reads: no plane of a used box sits on the grid's clamp values
+    # (a clamped plane would make the box tighter than the traversal's error bound assumes), and
+    # every quantised box contains its float box, as the device decodes it (origin + q * step in fp32
+    # arithmetic loses less than half a step, which the outward rounding by two steps covers).
+    q = b["qnodes"]
+    assert np.array_equal(q[:, 12:16].view(np.int32), refs)
+    planes = q[:, :12].reshape(-1, 6, 2)                          # [node][plane][pair]
+    q4 = np.stack([planes[..., 0] & 0xffff, planes[..., 0] >> 16, planes[..., 1] & 0xffff, planes[..., 1] >> 16], -1)
+    qlo, qhi = q4[:, 0:3].transpose(0, 2, 1), q4[:, 3:6].transpose(0, 2, 1)      # [node][child][xyz]
+    assert (qlo[used_slot] > 0).all() and (qhi[used_slot] < 65535).all()
+    o, st = b["grid_origin"].astype(np.float64), b["grid_step"].astype(np.float64)
+    assert (o + (qlo[used_slot] + 1) * st <= lo[used_slot]).all()
+    assert (o + (qhi[used_slot] - 1) * st >= hi[used_slot]).all()
     return b
 
 
@@ -103,6 +117,13 @@ def test_degenerate_inputs(pt):
     s["pos"][21] = [np.nan, 0, 0]
     b = check(pt, s)
     assert {20, 21} <= set(b["big_index"].tolist())  # unboundable: always tested
+    # A flat, elongated cloud: the builder's slack on every box follows the cloud's diagonal
+    # (1e-6 * 2e4 here) and exceeds 1/64 of the short axes' extent; the grid must still hold every plane.
+    s = scene(pt, rng, 600, n_big=0)
+    s["pos"][:, 0] = rng.uniform(-2e4, 2e4, 600)
+    s["pos"][:, 1:] = rng.uniform(-1e-3, 1e-3, (600, 2))
+    s["radius"] = 1e-3
+    assert check(pt, s) is not None
     # too many spheres that are far larger than the rest: no hierarchy, the scan is used
     s = scene(pt, rng, 400, n_big=80)
     assert pt.debug_build_bvh(s) is None

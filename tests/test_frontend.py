@@ -165,7 +165,7 @@ def parse_plan(text):
     return out
 
 
-@pytest.mark.parametrize("world,height,iterations", [(8, 2160, 1024), (8, 1080, 64), (3, 100, 64), (2, 16, 1), (5, 48, 3)])
+@pytest.mark.parametrize("world,height,iterations", [(8, 2160, 1024), (8, 1080, 64), (3, 100, 64), (2, 16, 1), (5, 48, 3), (7, 1080, 1000), (8, 33, 9)])
 def test_multi_gpu_partition_matches_the_python_sharding(exe, world, height, iterations):
     """`pt_headless --plan` (host/multi_gpu.hpp) against sharding.owned_bands / sample_range: the
     C++ and the Python front end cut a render the same way, every row and every iteration is
@@ -187,8 +187,7 @@ def test_multi_gpu_partition_matches_the_python_sharding(exe, world, height, ite
     for rank, first, n, rows in sample:
         assert rows == [(0, height)]
         covered[first:first + n] += 1
-        if iterations % world == 0:
-            assert (first, n) == sharding.sample_range(rank, world, iterations // world)
+        assert (first, n) == sharding.sample_range(rank, world, iterations)
     assert (covered[1:] == 1).all() and covered[0] == 0
     sizes = [n for _, _, n, _ in sample]
     assert max(sizes) - min(sizes) <= 1
@@ -215,6 +214,9 @@ def test_cli_multi_gpu_path_on_one_gpu(exe, tmp_path):
     assert read_pfm(tile).tobytes() == g["image"].tobytes()
     run(exe, *common, "--split", "sample", "--batch", 3, "--out", sample)
     np.testing.assert_allclose(read_pfm(sample), g["image"], rtol=2e-6 * 2, atol=1e-6)
+    # a device that fails before the closing reduce: the first error comes back, nobody waits in the collective
+    p = run(exe, *common, "--split", "sample", "--inject-failure", 0, "--out", sample, check=False)
+    assert p.returncode == 1 and "device 0: injected failure before the reduce" in p.stderr
     # more devices than the box has: a clean error, no crash
     p = run(exe, *common[:-1], 64, "--split", "tile", "--out", tile, check=False)
     assert p.returncode == 1 and "visible" in p.stderr

@@ -43,10 +43,13 @@ def _worker(rank, world, port, out_dir):
             O.oracle_render(*args, n_iterations=4, rect=(0, y0, 64, y1), buffer=img)
         return torch.from_numpy(img)
 
-    a = sharding.render_sample_split(render_sum, rank, world, 2, dist)
+    a = sharding.render_sample_split(render_sum, rank, world, 4, dist)
+    # 3 iterations over 2 ranks: rank 0 renders two, rank 1 one (the remainder goes to the first ranks)
+    a3 = sharding.render_sample_split(render_sum, rank, world, 3, dist)
     b = sharding.render_tile_split(render_bands, rank, world, dist)
     if rank == 0:
         np.save(os.path.join(out_dir, "sample.npy"), a.numpy())
+        np.save(os.path.join(out_dir, "sample3.npy"), a3.numpy())
         np.save(os.path.join(out_dir, "tile.npy"), b.numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -61,12 +64,24 @@ def test_two_rank_gloo_sharding(tmp_path):
     # tile split: bit-exact; sample split: summation order differs -> rounding tolerance
     assert tile.tobytes() == g["image"].tobytes()
     np.testing.assert_allclose(sample, g["image"], rtol=4e-6, atol=1e-6)
+    # the uneven split against one rank rendering the same three iterations
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    whole, _, _, _ = O.oracle_render(g["camera_pod"], g["materials"], g["spheres"], g["lights"], int(g["seed"]),
+                                     int(g["max_bounces"]), first_iteration=1, n_iterations=3)
+    np.testing.assert_allclose(np.load(tmp_path / "sample3.npy"), whole, rtol=4e-6, atol=1e-6)
 
 
 def test_plans():
     sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
-    assert sharding.sample_range(0, 8, 128) == (1, 128)
-    assert sharding.sample_range(7, 8, 128) == (897, 128)
+    assert sharding.sample_range(0, 8, 1024) == (1, 128)
+    assert sharding.sample_range(7, 8, 1024) == (897, 128)
+    # remainders go to the first ranks; every iteration exactly once; a rank may get none
+    assert [sharding.sample_range(r, 3, 64) for r in range(3)] == [(1, 22), (23, 21), (44, 21)]
+    assert [sharding.sample_range(r, 5, 3) for r in range(5)] == [(1, 1), (2, 1), (3, 1), (4, 0), (4, 0)]
+    for world, total in ((8, 1000), (7, 64), (3, 2), (4, 0)):
+        covered = [i for r in range(world) for f, n in [sharding.sample_range(r, world, total)] for i in range(f, f + n)]
+        assert covered == list(range(1, total + 1))
     with pytest.raises(ValueError):
         sharding.sample_range(8, 8, 1)
     bands = [sharding.owned_bands(1080, 16, r, 8) for r in range(8)]

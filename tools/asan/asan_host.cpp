@@ -6,6 +6,7 @@
 #include "pt_bvh.hpp"
 #include "pt_checkpoint.hpp"
 #include "scene_file.hpp"
+#include "shard_plan.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -13,6 +14,7 @@
 #include <random>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 static int g_failures = 0;
@@ -193,6 +195,40 @@ static void checkpoints(const std::string &dir)
     CHECK(!WritePFM(dir + "/no/such/dir/i.pfm", img.data(), 7, 5));
 }
 
+// The meeting point of the sharded render's host threads: everyone learns whether anyone failed,
+// however the arrivals interleave, and no thread is left waiting.
+static void rendezvous()
+{
+    for (uint32_t world : {1u, 2u, 8u}) {
+        for (int failing = -1; failing < (int)world; ++failing) {
+            ShardRendezvous r(world);
+            std::vector<int> verdict(world, -1);
+            std::vector<std::thread> threads;
+            for (uint32_t k = 0; k < world; ++k)
+                threads.emplace_back([&, k] {
+                    if (k % 3 == 1) std::this_thread::yield();
+                    verdict[k] = r.Arrive((int)k != failing) ? 1 : 0;
+                });
+            for (auto &t : threads) t.join();
+            for (uint32_t k = 0; k < world; ++k) CHECK(verdict[k] == (failing < 0 ? 1 : 0));
+        }
+    }
+    // the partition: every iteration and every row exactly once
+    for (uint32_t world : {1u, 3u, 8u}) {
+        std::vector<int> it(1001, 0), row(1080, 0);
+        for (uint32_t k = 0; k < world; ++k) {
+            const ShardPlan s = MakeShardPlan(SplitMode::Sample, k, world, 1000, 1080);
+            for (uint32_t i = 0; i < s.n_iterations; ++i) ++it[s.first_iteration + i];
+            const ShardPlan t = MakeShardPlan(SplitMode::Tile, k, world, 1000, 1080);
+            for (const auto &yy : t.rows) for (uint32_t y = yy.first; y < yy.second; ++y) ++row[y];
+        }
+        bool once = it[0] == 0;
+        for (int i = 1; i <= 1000; ++i) once = once && it[i] == 1;
+        for (int y = 0; y < 1080; ++y) once = once && row[y] == 1;
+        CHECK(once);
+    }
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: asan_host <scratch directory>\n"); return 2; }
@@ -200,6 +236,7 @@ int main(int argc, char **argv)
     cameras();
     bvhs();
     checkpoints(argv[1]);
+    rendezvous();
     printf("asan_host: %d failure(s)\n", g_failures);
     return g_failures ? 1 : 0;
 }

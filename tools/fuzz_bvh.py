@@ -47,7 +47,7 @@ def random_scene(seed):
     lights["u_bits"][0, 0] = len(walls) - 1
     lights["intensity"] = [[12, 12, 12]]
     balls = np.zeros(n, pt.SPHERE_DTYPE)
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 5)
     if kind == 0:      # uniform cloud
         balls["pos"] = centre + rng.uniform(-0.85 * half, 0.85 * half, (n, 3))
     elif kind == 1:    # clumps
@@ -55,6 +55,8 @@ def random_scene(seed):
         balls["pos"] = centre + seeds[rng.integers(0, len(seeds), n)] + rng.normal(0, 0.04 * half, (n, 3))
     elif kind == 2:    # a sheet
         balls["pos"] = centre + rng.uniform(-0.85 * half, 0.85 * half, (n, 3)) * np.array([1, 0.02, 1])
+    elif kind == 4:    # a flat, elongated cloud: the boxes' slack exceeds the short axes' extent
+        balls["pos"] = centre + rng.uniform(-0.85 * half, 0.85 * half, (n, 3)) * np.array([25, 1e-6, 3e-3])
     else:              # a regular grid (many exact ties in the split planes)
         k = int(np.ceil(n ** (1 / 3)))
         g = np.stack(np.meshgrid(*[np.arange(k)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
