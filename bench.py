@@ -216,14 +216,27 @@ def self_launch(n_gpus: int) -> int:
     return proc.returncode
 
 
-def pmc_summary(tag_path: str):
-    """Issue-slot utilisation and active-lane fraction of the render kernel from the committed PMC
-    passes of this same command (profiles/pmc_*.json, written by tools/summarize_prof.py)."""
+PMC_FIELDS = ("hbm_bytes_per_step", "valu_issue_util", "active_lane_frac", "wait_frac")
+
+
+def pmc_summary(tag_path: str, build_id: str):
+    """Issue-slot utilisation, active-lane fraction and HBM bytes of the render kernel from the
+    committed PMC passes of this same command (profiles/pmc_*.json, written by
+    tools/summarize_prof.py; rocprofv3 cannot be run from inside the benchmark).  The file carries
+    the build id of the library the counters were taken from: for another build the counters are
+    not quoted (all None) and `counters_from` says why.  Returns (counters, counters_from)."""
+    rel = os.path.relpath(tag_path, ROOT)
     if not os.path.exists(tag_path):
-        return {}
+        return {}, {"file": None, "note": f"no committed PMC pass for this launch ({rel})"}
     with open(tag_path) as f:
         v = json.load(f)
-    return {k: v[k] for k in ("hbm_bytes_per_step", "valu_issue_util", "active_lane_frac", "wait_frac") if k in v}
+    source = {"file": rel, "tag": v.get("tag"), "build_id": v.get("build_id"), "this_build_id": build_id}
+    if v.get("build_id") != build_id:
+        source["stale"] = True
+        source["note"] = "counters were taken from another build of libptmi.so: not quoted"
+        return {}, source
+    source["stale"] = False
+    return {k: v[k] for k in PMC_FIELDS if k in v}, source
 
 
 def main():
@@ -241,6 +254,9 @@ def main():
     ap.add_argument("--integrator", default="path", choices=["path", "nee"],
                     help="path: the reference's Trace (the headline metric); nee: opt-in direct-light sampling "
                          "with MIS (bounces then include the shadow rays)")
+    ap.add_argument("--serial-launches", action="store_true",
+                    help="profiling: one set of batch buffers on one stream (PT_TUNE_BUFFER_SETS 1), so that the "
+                         "launches of a step run one after the other and a kernel trace of the step is additive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="N = 1, default workload: do not append the short runs of the other workloads")
@@ -294,6 +310,8 @@ def main():
     tr.SetKernelVariant(args.variant)
     tr.SetAccel(pt.ACCEL_AUTO if args.accel == "auto" else pt.ACCEL_BRUTE_FORCE)
     tr.SetIntegrator(pt.INTEGRATOR_NEE_MIS if args.integrator == "nee" else pt.INTEGRATOR_PATH)
+    if args.serial_launches:
+        tr.SetTuning(pt.TUNE_BUFFER_SETS, 1)
     bvh = args.accel == "auto" and tr.AccelNodes() > 0
     # what PT_VARIANT_AUTO resolves to is asked of the library after the warm-up (pt_last_launch)
     tr.SetStream(torch.cuda.current_stream().cuda_stream)
@@ -432,7 +450,9 @@ def main():
     }
     launch_tag, launch_kernel = LAUNCH_NAMES.get(launch, ("none", "none"))
     tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}{'_bvh' if bvh else ''}_{launch_tag}.json")
-    pmc = pmc_summary(tpath) if args.integrator == "path" else {}
+    build_id = pt.build_id()
+    pmc, counters_from = pmc_summary(tpath, build_id) if args.integrator == "path" and not args.serial_launches else \
+        ({}, {"file": None, "note": "no committed PMC pass for this command"})
     traffic = pmc.get("hbm_bytes_per_step")
     achieved = rays_per_launch * fpr / (launch_ms * 1e-3) / 1e12 if fpr else None
 
@@ -448,7 +468,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl["label"], "paths_per_step_per_gpu": wl["width"] * wl["height"] * 4 * n_it // (world if tile_split else 1),
+            "build_id": build_id,
+            "config": {"workload": wl["label"], "serial_launches": bool(args.serial_launches), "paths_per_step_per_gpu": wl["width"] * wl["height"] * 4 * n_it // (world if tile_split else 1),
                        "bounces_per_step_per_gpu": rays_per_launch, "spheres": int(len(sph)),
                        "parallelism": "single" if world == 1 else
                                       f"{'tile (16-row bands)' if tile_split else 'sample-range'} split x{world} + "
@@ -466,6 +487,7 @@ def main():
                          "valu_issue_util": pmc.get("valu_issue_util"),
                          "active_lane_frac": pmc.get("active_lane_frac"),
                          "wait_frac": pmc.get("wait_frac"),
+                         "counters_from": counters_from,
                          "kernel": launch_kernel,
                          "launch_ms": launch_ms,
                          "flops_per_bounce": fpr, "bounces_per_launch": rays_per_launch},
@@ -477,8 +499,8 @@ def main():
             # The other benchmark configurations, a few steps each with the defaults, so that one
             # run of this file measures all of them (not part of `value`, outside its timed region).
             others = []
-            for name, accel, k in (("mixed16", "auto", 3), ("synth10k", "auto", 2), ("synth10k", "brute", 1),
-                                   ("demo4k", "auto", 1)):
+            for name, accel, k in (("mixed16", "auto", 5), ("synth10k", "auto", 4), ("synth10k", "brute", 3),
+                                   ("demo4k", "auto", 3)):
                 try:
                     others.append(measure_other_workload(pt, torch, name, accel, k))
                 except Exception as e:   # the headline line must not depend on these

@@ -45,6 +45,8 @@ INTEGRATOR_PATH, INTEGRATOR_NEE_MIS = 0, 1
 LAUNCH_NONE, LAUNCH_MEGAKERNEL, LAUNCH_MEGAKERNEL_STEALING, LAUNCH_WAVEFRONT, LAUNCH_WAVEFRONT_WHOLE_PATHS, LAUNCH_PATH_POOL = range(6)
 TUNE_REGEN_MIN_IDLE, TUNE_CAMERA_RAY_RING, TUNE_STEAL_UNIT, TUNE_ITERATION_RANGES, TUNE_WAVEFRONT_REFILL = 0, 1, 2, 3, 4
 TUNE_BVH_NODE_STEPS, TUNE_BVH_STACK, TUNE_WAVEFRONT_BATCH, TUNE_WAVEFRONT_WHOLE_PATHS, TUNE_POOL_ITERATIONS = 5, 6, 7, 8, 9
+TUNE_BUFFER_SETS = 10
+TUNE_POOL_WORKGROUPS = 11
 PT_OK, PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_DEVICE, PT_ERR_NOMEM = 0, -1, -2, -3, -4
 
 # Every symbol include/ptmi.h declares: (name, restype, argtypes)
@@ -57,6 +59,8 @@ ABI = [
     ("pt_last_error", ctypes.c_char_p, [_vp]),
     ("pt_run", _i32, [_vp, _vp, _i32]),
     ("pt_run_n", _i32, [_vp, _vp, _u32, _i32]),
+    ("pt_run_async", _i32, [_vp, _vp, _u32]),
+    ("pt_wait", _i32, [_vp]),
     ("pt_run_n_noalloc", _i32, [_vp, _vp, _u32, _i32]),
     ("pt_reset", _i32, [_vp]),
     ("pt_iteration", _u32, [_vp]),
@@ -122,6 +126,14 @@ def _share_hip_runtime_with_torch() -> None:
         path = os.path.join(libdir, name)
         if os.path.exists(path):
             ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
+def build_id() -> str:
+    """Identifies the build of libptmi.so this module loads: the first 16 hex digits of the file's
+    SHA-256.  Profiles record it, so that counters taken from one build are not quoted for another."""
+    import hashlib
+    with open(LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def load_library() -> ctypes.CDLL:
@@ -310,6 +322,14 @@ class Pathtracer:
 
     def RunN(self, dev_buffer, n_iterations: int, sync: bool = True) -> None:
         self._check(self._lib.pt_run_n(self._h, _vp(_devptr(dev_buffer, self)), n_iterations, int(sync)))
+
+    def RunAsync(self, dev_buffer, n_iterations: int = 1) -> None:
+        """Run() without the wait (pt_run_async): consecutive calls overlap on the device; Wait()
+        ends the series.  Same image as Run / RunN, bit for bit."""
+        self._check(self._lib.pt_run_async(self._h, _vp(_devptr(dev_buffer, self)), n_iterations))
+
+    def Wait(self) -> None:
+        self._check(self._lib.pt_wait(self._h))
 
     def RunNNoAlloc(self, dev_buffer, n_iterations: int, sync: bool = True) -> None:
         """RunN through the entry point that allocates no device memory (static scratch)."""

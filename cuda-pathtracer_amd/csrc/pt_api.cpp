@@ -75,9 +75,17 @@ struct pt_context {
     } wf_pipe[2];
     hipStream_t wf_stream2;
     hipEvent_t wf_fork;
+    // pt_run_async: consecutive CALLS alternate between the two buffer sets and streams the way the
+    // batches of one call do.  async_series: a series of such calls is open (wf_fork marks where the
+    // caller's stream stood when it began); async_set: the set the next call takes; async_on_stream2:
+    // the series' last call went to the second stream, which the caller's stream has not waited for yet.
+    bool async_series, async_on_stream2, async_forked;
+    int async_set;
     uint32_t wf_target_mpaths;   // paths per wavefront batch in units of 2^20 (0: kWfTargetPaths)
     int wf_whole_paths;          // BVH scenes with dynamic fetch, PT_TUNE_WAVEFRONT_WHOLE_PATHS: -1 chosen per render
     int wf_n_queues;             // path queues per buffer set (0, 1 or 2)
+    int pool_workgroups;         // PT_TUNE_POOL_WORKGROUPS: persistent workgroups per CU of a pool launch, 0 = default
+    int wf_buffer_sets;          // PT_TUNE_BUFFER_SETS: 0 two sets on two streams, 1 one set on the caller's stream
     int pool_max_iterations;     // resident scenes: launches of up to this many iterations go through the path pool
     int last_launch;             // PT_LAUNCH_* of the last render
     uint32_t wf_sub_capacity;   // paths per sub-queue the buffers were sized for
@@ -120,6 +128,21 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard &) = delete;
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
+
+// Ends a series of pt_run_async calls: the caller's stream gets behind everything the series put
+// on the second stream.  The resolves of consecutive calls wait for each other, so the last call's
+// resolve is behind all of them: when it ran on the caller's stream nothing is left to wait for.
+// Every entry point that uses the caller's stream (or frees what the launches use) calls this first.
+static hipError_t join_async(pt_context *h)
+{
+    if (h->async_on_stream2) {
+        const hipError_t e = hipStreamWaitEvent(h->stream, h->wf_pipe[1].resolved, 0);
+        if (e != hipSuccess) return e;
+    }
+    h->async_series = h->async_on_stream2 = h->async_forked = false;
+    h->async_set = 0;
+    return hipSuccess;
+}
 
 // Scenes are staged whole in LDS (spheres, materials, lights) when they are small enough;
 // otherwise spheres stream through an LDS tile and the rest is read from device memory.
@@ -202,9 +225,13 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     memset(h->wf_pipe, 0, sizeof h->wf_pipe);
     h->wf_stream2 = nullptr;
     h->wf_fork = nullptr;
+    h->async_series = h->async_on_stream2 = h->async_forked = false;
+    h->async_set = 0;
     h->wf_target_mpaths = 0;
     h->wf_whole_paths = -1;
     h->wf_n_queues = 0;
+    h->wf_buffer_sets = 0;
+    h->pool_workgroups = 0;
     h->pool_max_iterations = 1 << 30;
     h->last_launch = PT_LAUNCH_NONE;
     h->wf_sub_capacity = 0;
@@ -302,6 +329,9 @@ static int upload_bvh(pt_context *h, const std::vector<float4> &sph, const pt_sp
 static void free_wavefront(pt_context *h)
 {
     if (h->wf_stream2) (void)hipStreamSynchronize(h->wf_stream2);
+    // nothing is left on the second stream: an open series of pt_run_async calls has nothing to join
+    h->async_series = h->async_on_stream2 = h->async_forked = false;
+    h->async_set = 0;
     for (auto &pipe : h->wf_pipe) {
         for (auto &q : pipe.queue) {
             if (q.a) (void)hipFree(q.a);
@@ -321,6 +351,7 @@ int pt_destroy(pt_handle h)
 {
     if (!h) return PT_ERR_INVALID;
     DeviceGuard on_device(h->device);
+    if (h->async_series) (void)join_async(h);
     (void)hipStreamSynchronize(h->stream);
     free_scene(h);
     free_wavefront(h);
@@ -384,6 +415,7 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
         if (lights[i].type == PT_AREA_LIGHT && lights[i].u.prim_id >= n_spheres)
             return fail(h, PT_ERR_INVALID, "pt_init_scene: light %u sits on sphere %u of %u", i, lights[i].u.prim_id,
                         n_spheres);
+    if (h->async_series) PT_HIP(h, join_async(h));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     free_scene(h);
 
@@ -470,6 +502,8 @@ int pt_set_camera(pt_handle h, const pt_camera_pod *camera)
 int pt_set_stream(pt_handle h, void *hip_stream)
 {
     if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
+    if (h->async_series) PT_HIP(h, join_async(h));   // on the stream the series was started on
     h->stream = (hipStream_t)hip_stream;
     return PT_OK;
 }
@@ -579,6 +613,7 @@ int pt_accel_stats(pt_handle h, uint64_t out[32])
     DeviceGuard on_device(h->device);
     memset(out, 0, 32 * sizeof(uint64_t));
     if (!h->d_bvh) return PT_OK;
+    if (h->async_series) PT_HIP(h, join_async(h));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     PT_HIP(h, hipMemcpy(out, h->bvh.stats, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     PT_HIP(h, hipMemset(h->bvh.stats, 0, 32 * sizeof(uint64_t)));
@@ -589,6 +624,7 @@ int pt_lane_stats(pt_handle h, uint64_t out[64])
 {
     if (!h || !out) return PT_ERR_INVALID;
     DeviceGuard on_device(h->device);
+    if (h->async_series) PT_HIP(h, join_async(h));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     unsigned long long v[64];
     PT_HIP(h, read_lane_stats(v));
@@ -659,6 +695,14 @@ int pt_debug_set_tuning(pt_handle h, int key, int value)
     case PT_TUNE_WAVEFRONT_WHOLE_PATHS:
         if (value < -1 || value > 2) break;
         h->wf_whole_paths = value;
+        return PT_OK;
+    case PT_TUNE_POOL_WORKGROUPS:
+        if (value < 0 || value > 8) break;
+        h->pool_workgroups = value;
+        return PT_OK;
+    case PT_TUNE_BUFFER_SETS:
+        if (value != 0 && value != 1) break;
+        h->wf_buffer_sets = value;
         return PT_OK;
     default:
         return fail(h, PT_ERR_INVALID, "pt_debug_set_tuning: unknown key %d", key);
@@ -861,14 +905,21 @@ static uint64_t wavefront_queues(int mode) { return mode == 0 ? 2 : mode == 2 ? 
 // handle's memory limit; 0 when not even one iteration fits.  A render of more iterations than
 // that runs as several batches alternating between two buffer sets of half the size each
 // (*sets = 2); when half the memory does not hold one iteration, one set takes all of it.
-static uint32_t plan_batches(uint64_t paths_per_it, uint32_t n_iterations, uint64_t per_path, uint64_t memory_limit,
-                             uint32_t target_mpaths, uint32_t *sets)
+// Paths in flight the batch buffers (both sets together) are planned for.
+static uint64_t plan_target(uint64_t per_path, uint64_t memory_limit, uint32_t target_mpaths)
 {
     uint64_t target = target_mpaths ? (uint64_t)target_mpaths << 20 : kWfTargetBytes / per_path;
     if (memory_limit && memory_limit / per_path < target) target = memory_limit / per_path;
+    return target;
+}
+
+static uint32_t plan_batches(uint64_t paths_per_it, uint32_t n_iterations, uint64_t per_path, uint64_t memory_limit,
+                             uint32_t target_mpaths, uint32_t *sets, bool one_set = false)
+{
+    const uint64_t target = plan_target(per_path, memory_limit, target_mpaths);
     uint32_t n_sets = 2;
     uint64_t batch_it = target / 2 / paths_per_it;
-    if (batch_it < 1 || batch_it >= n_iterations) {
+    if (batch_it < 1 || batch_it >= n_iterations || one_set) {   // one_set: the same batches, one after the other
         n_sets = 1;
         batch_it = batch_it < 1 ? target / paths_per_it : batch_it;
         if (batch_it < 1) batch_it = memory_limit ? 0 : 1;
@@ -882,14 +933,42 @@ static uint32_t plan_batches(uint64_t paths_per_it, uint32_t n_iterations, uint6
     return (uint32_t)batch_it;
 }
 
+static uint32_t wavefront_target_mpaths(const pt_context *h, int mode)
+{
+    return h->wf_target_mpaths ? h->wf_target_mpaths : mode == 3 ? 266u : 0;
+}
+
+// Path-pool launches of a pt_run_async series: persistent workgroups per CU.  A launch of few
+// paths is mostly start-up and tail; with about half the resident set per launch, two consecutive
+// calls' launches are resident side by side and one's tail runs under the other's body.  Measured
+// at 1080p, demo scene, 64 calls of one iteration + one wait, workgroups per CU 2..8: 29.3, 25.1,
+// 25.3, 25.0, 28.2, 28.2, 28.2 ms (one launch of 64 iterations: 24.5 ms); 32 calls of two: 28.8,
+// 24.7, 25.0, 24.8, 26.2, 26.2, 26.2; 16 calls of four: 5: 24.6, 8: 25.1; the 71-sphere scene at
+// depth 16: 64 calls 5: 62.9, 8: 63.4, 16 calls of four 5: 62.1, 8: 61.4.  So: five for calls of
+// up to 20 Mi paths (two iterations at 1080p), the full set beyond.
+static int async_pool_workgroups(uint64_t paths_per_call)
+{
+    return paths_per_call <= (20ull << 20) ? 5 : 0;
+}
+
+// pt_run_async: can a call of n_iterations be ONE batch in one of two buffer sets, so that
+// consecutive calls alternate between the sets?  (Half the planned paths in flight hold it.)
+static bool async_call_alternates(const pt_context *h, int mode, uint64_t paths_per_it, uint32_t n_iterations)
+{
+    if (h->wf_buffer_sets == 1 || n_iterations >= (1u << 20)) return false;
+    const uint64_t half = plan_target(wavefront_bytes_per_path(mode), h->memory_limit, wavefront_target_mpaths(h, mode)) / 2;
+    return half / paths_per_it >= n_iterations && (uint64_t)n_iterations * paths_per_it <= 0xffffffffull;
+}
+
 static uint32_t wavefront_batch_iterations(const pt_context *h, int mode, uint64_t paths_per_it, uint32_t n_iterations, uint32_t *sets = nullptr)
 {
     // The path pool: 256 Mi paths in flight over the two sets (3.3 GB; 16 iterations per batch at
     // 1080p).  Measured on the 1080p x 64 demo render, iterations per batch: 32 24.57 ms, 16 24.57,
     // 8 24.69, 4 25.17, 2 26.34 -- the resolve reads only the entries of the paths that met a light,
     // so a batch costs little beyond its launches.
-    const uint32_t target_mpaths = h->wf_target_mpaths ? h->wf_target_mpaths : mode == 3 ? 266u : 0;
-    return plan_batches(paths_per_it, n_iterations, wavefront_bytes_per_path(mode), h->memory_limit, target_mpaths, sets);
+    const uint32_t target_mpaths = wavefront_target_mpaths(h, mode);
+    return plan_batches(paths_per_it, n_iterations, wavefront_bytes_per_path(mode), h->memory_limit, target_mpaths, sets,
+                        h->wf_buffer_sets == 1);
 }
 
 int pt_debug_plan_batches(uint32_t width, uint32_t height, uint32_t band_rows, uint32_t band_rank, uint32_t band_world,
@@ -971,6 +1050,7 @@ static void fill_wavefront(const pt_context *h, WavefrontParams &p)
     p.dynamic_fetch = h->wf_dynamic_fetch;
     p.sub_capacity = h->wf_sub_capacity;
     p.x0 = 0; p.y0 = 0; p.rect_w = p.cam.width; p.rect_h = p.cam.height;
+    p.pool_workgroups_per_cu = h->pool_workgroups;
 }
 
 // One batch in buffer set `set` on `stream`: a launch per bounce over the compacted queues, then
@@ -1009,7 +1089,10 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, int mode, s
 
 // Wavefront variant: batches of whole iterations; per batch one launch per bounce + a resolve.
 // Returns PT_ERR_NOMEM (nothing rendered, nothing held) when the queues do not fit.
-static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
+// async_call (pt_run_async): a call that fits one buffer set is one batch, and consecutive calls
+// alternate between the two sets and streams as the batches of one call do; the caller's stream is
+// not made to wait for the second stream (join_async does that later).
+static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations, bool async_call)
 {
     const int mode = wavefront_mode(h, n_iterations);
     const uint32_t rows = owned_rows(h);
@@ -1022,10 +1105,13 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
     if (h->iteration + (uint64_t)n_iterations >= (1u << 30))
         return fail(h, PT_ERR_INVALID, "wavefront variant: iteration numbers must stay below 2^30");
     uint32_t sets = 1;
-    const uint32_t batch_it = wavefront_batch_iterations(h, mode, paths_per_it, n_iterations, &sets);
+    uint32_t batch_it = wavefront_batch_iterations(h, mode, paths_per_it, n_iterations, &sets);
     if (batch_it == 0)
         return fail(h, PT_ERR_NOMEM, "wavefront variant: one iteration needs %llu MiB of queues, the memory limit is %llu MiB",
                     (unsigned long long)(paths_per_it * wavefront_bytes_per_path(mode) >> 20), (unsigned long long)(h->memory_limit >> 20));
+    const bool alternate = async_call && async_call_alternates(h, mode, paths_per_it, n_iterations);
+    if (alternate) { batch_it = n_iterations; sets = 2; }
+    else if (h->async_series) PT_HIP(h, join_async(h));   // this call runs in the caller's stream's order
     size_t counts_bytes = 0;
     const int rc = ensure_wavefront(h, mode, paths_per_it * batch_it, wavefront_sub_capacity(h->camera.width, rows, batch_it),
                                     sets, &counts_bytes);
@@ -1039,32 +1125,67 @@ static int enqueue_wavefront(pt_context *h, float *dbuf, uint32_t n_iterations)
     p.rect_h = rows;
     if (h->band_world > 1) { p.band_rows = h->band_rows; p.band_rank = h->band_rank; p.band_world = h->band_world; }
 
-    PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
-    if (sets > 1) {   // the second stream starts after what the caller's stream holds so far
-        PT_HIP(h, hipEventRecord(h->wf_fork, h->stream));
-        PT_HIP(h, hipStreamWaitEvent(h->wf_stream2, h->wf_fork, 0));
-    }
-    uint32_t done = 0;
-    int set = 0;
-    hipEvent_t before = nullptr;
-    while (done < n_iterations) {
-        const uint32_t n = n_iterations - done < batch_it ? n_iterations - done : batch_it;
-        p.first_iteration = h->iteration + done + 1;
-        p.n_iterations = n;
-        p.overwrite = h->accum_mode == PT_ACCUM_RUNNING_MEAN ? (p.first_iteration == 1)
-                                                             : ((h->fresh && done == 0) ? 1 : 0);
-        const int brc = launch_wavefront_batch(h, p, mode, counts_bytes, set, set ? h->wf_stream2 : h->stream, before, sets > 1);
-        if (brc != PT_OK) {   // nothing of this call may still run on the second stream when the caller sees the error
-            if (sets > 1) (void)hipStreamSynchronize(h->wf_stream2);
+    if (alternate) {
+        // One batch in the set whose turn it is.  The series' first call marks where the caller's stream
+        // stood (the second stream starts behind that, once); a call's resolve waits for the resolve of
+        // the call before it, which ran in the other set: the frame buffer takes the iterations in order.
+        if (!h->async_series) {
+            PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
+            PT_HIP(h, hipEventRecord(h->wf_fork, h->stream));
+            h->async_series = true;
+            h->async_forked = false;
+            h->async_set = 0;
+        }
+        const int set = h->async_set;
+        if (set == 1 && !h->async_forked) {
+            PT_HIP(h, hipStreamWaitEvent(h->wf_stream2, h->wf_fork, 0));
+            h->async_forked = true;
+        }
+        p.first_iteration = h->iteration + 1;
+        p.n_iterations = n_iterations;
+        p.overwrite = h->accum_mode == PT_ACCUM_RUNNING_MEAN ? (p.first_iteration == 1) : (h->fresh ? 1 : 0);
+        p.pool_workgroups_per_cu = h->pool_workgroups ? h->pool_workgroups : async_pool_workgroups(paths_per_it * n_iterations);
+        // the other set's event is that of the call before this one, if the series has had one there
+        hipEvent_t before = nullptr;
+        if (set == 1) before = h->wf_pipe[0].resolved;
+        else if (h->async_forked) before = h->wf_pipe[1].resolved;
+        const int brc = launch_wavefront_batch(h, p, mode, counts_bytes, set, set ? h->wf_stream2 : h->stream, before, true);
+        if (brc != PT_OK) {
+            (void)hipStreamSynchronize(h->wf_stream2);
+            h->async_series = h->async_on_stream2 = h->async_forked = false;
+            h->async_set = 0;
             return brc;
         }
-        before = sets > 1 ? h->wf_pipe[set].resolved : nullptr;
-        done += n;
-        if (sets > 1) set ^= 1;
+        h->async_on_stream2 = set == 1;
+        h->async_set = set ^ 1;
+    } else {
+        PT_HIP(h, hipEventRecord(h->ev_start, h->stream));
+        if (sets > 1) {   // the second stream starts after what the caller's stream holds so far
+            PT_HIP(h, hipEventRecord(h->wf_fork, h->stream));
+            PT_HIP(h, hipStreamWaitEvent(h->wf_stream2, h->wf_fork, 0));
+        }
+        uint32_t done = 0;
+        int set = 0;
+        hipEvent_t before = nullptr;
+        while (done < n_iterations) {
+            const uint32_t n = n_iterations - done < batch_it ? n_iterations - done : batch_it;
+            p.first_iteration = h->iteration + done + 1;
+            p.n_iterations = n;
+            p.overwrite = h->accum_mode == PT_ACCUM_RUNNING_MEAN ? (p.first_iteration == 1)
+                                                                 : ((h->fresh && done == 0) ? 1 : 0);
+            const int brc = launch_wavefront_batch(h, p, mode, counts_bytes, set, set ? h->wf_stream2 : h->stream, before, sets > 1);
+            if (brc != PT_OK) {   // nothing of this call may still run on the second stream when the caller sees the error
+                if (sets > 1) (void)hipStreamSynchronize(h->wf_stream2);
+                return brc;
+            }
+            before = sets > 1 ? h->wf_pipe[set].resolved : nullptr;
+            done += n;
+            if (sets > 1) set ^= 1;
+        }
+        // the caller's stream ends behind the last resolve (its own, which waited for the other's, or the other's)
+        if (before && before == h->wf_pipe[1].resolved) PT_HIP(h, hipStreamWaitEvent(h->stream, before, 0));
+        PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
     }
-    // the caller's stream ends behind the last resolve (its own, which waited for the other's, or the other's)
-    if (before && before == h->wf_pipe[1].resolved) PT_HIP(h, hipStreamWaitEvent(h->stream, before, 0));
-    PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
     h->timed = true;
     h->last_launch = mode == 3 ? PT_LAUNCH_PATH_POOL : mode == 0 ? PT_LAUNCH_WAVEFRONT : PT_LAUNCH_WAVEFRONT_WHOLE_PATHS;
     h->iteration += n_iterations;
@@ -1216,8 +1337,8 @@ static int enqueue_megakernel(pt_context *h, float *dbuf, uint32_t n_iterations,
     return PT_OK;
 }
 
-// Enqueue n iterations on the handle's stream.
-static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
+// Enqueue n iterations on the handle's stream (async_call: see enqueue_wavefront).
+static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations, bool async_call = false)
 {
     if (!h->scene_ready) return fail(h, PT_ERR_STATE, "render before pt_init_scene");
     if (!dbuf) return fail(h, PT_ERR_INVALID, "render: buffer is NULL");
@@ -1228,10 +1349,11 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations)
     if (h->wavefront && !wavefront_indexing_ok(h))
         return fail(h, PT_ERR_INVALID, "the wavefront variant takes frames of fewer than 2^20 rows and band_rows * world below 2^30");
     if (takes_wavefront(h, h->iteration + (uint64_t)n_iterations, n_iterations)) {
-        const int rc = enqueue_wavefront(h, dbuf, n_iterations);
+        const int rc = enqueue_wavefront(h, dbuf, n_iterations, async_call);
         // PT_VARIANT_AUTO: when the queues cannot be had the megakernel renders the same image
         if (rc != PT_ERR_NOMEM || h->wavefront) return rc;
     }
+    if (h->async_series) PT_HIP(h, join_async(h));
     return enqueue_megakernel(h, dbuf, n_iterations, nullptr);
 }
 
@@ -1245,10 +1367,29 @@ int pt_run_n(pt_handle h, float *device_buffer, uint32_t n_iterations, int sync)
     return PT_OK;
 }
 
+int pt_run_async(pt_handle h, float *device_buffer, uint32_t n_iterations)
+{
+    if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
+    return enqueue(h, device_buffer, n_iterations, true);
+}
+
+int pt_wait(pt_handle h)
+{
+    if (!h) return PT_ERR_INVALID;
+    DeviceGuard on_device(h->device);
+    const bool series = h->async_series;
+    PT_HIP(h, join_async(h));
+    if (series) PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));   // pt_last_kernel_ms: the whole series
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
 int pt_run_n_noalloc(pt_handle h, float *device_buffer, uint32_t n_iterations, int sync)
 {
     if (!h) return PT_ERR_INVALID;
     DeviceGuard on_device(h->device);
+    if (h->async_series) PT_HIP(h, join_async(h));
     if (!h->scene_ready) return fail(h, PT_ERR_STATE, "render before pt_init_scene");
     if (!device_buffer) return fail(h, PT_ERR_INVALID, "render: buffer is NULL");
     if (h->wavefront)
@@ -1291,6 +1432,7 @@ int pt_read_image(pt_handle h, const float *device_buffer, float *host_rgb)
     if (!h) return PT_ERR_INVALID;
     DeviceGuard on_device(h->device);
     if (!device_buffer || !host_rgb) return fail(h, PT_ERR_INVALID, "pt_read_image: NULL pointer");
+    if (h->async_series) PT_HIP(h, join_async(h));
     const size_t bytes = (size_t)h->camera.width * h->camera.height * 3 * sizeof(float);
     PT_HIP(h, hipMemcpyAsync(host_rgb, device_buffer, bytes, hipMemcpyDeviceToHost, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -1339,6 +1481,7 @@ int pt_load_checkpoint(pt_handle h, float *device_buffer, const char *path)
     std::string err;
     const int rc = checkpoint_read(path, checkpoint_meta(h), &img, &iteration, &err);
     if (rc != kCkpOk) return fail(h, rc == kCkpMismatch ? PT_ERR_STATE : PT_ERR_INVALID, "pt_load_checkpoint: %s", err.c_str());
+    if (h->async_series) PT_HIP(h, join_async(h));
     PT_HIP(h, hipMemcpyAsync(device_buffer, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     h->iteration = iteration;
@@ -1350,6 +1493,7 @@ int pt_ray_count(pt_handle h, uint64_t *out)
 {
     if (!h || !out) return PT_ERR_INVALID;
     DeviceGuard on_device(h->device);
+    if (h->async_series) PT_HIP(h, join_async(h));
     unsigned long long v = 0;
     PT_HIP(h, hipMemcpyAsync(&v, h->d_ray_counter, sizeof v, hipMemcpyDeviceToHost, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -1361,6 +1505,7 @@ int pt_reset_counters(pt_handle h)
 {
     if (!h) return PT_ERR_INVALID;
     DeviceGuard on_device(h->device);
+    if (h->async_series) PT_HIP(h, join_async(h));
     PT_HIP(h, hipMemsetAsync(h->d_ray_counter, 0, sizeof(unsigned long long), h->stream));
     return PT_OK;
 }
@@ -1377,6 +1522,10 @@ int pt_last_kernel_ms(pt_handle h, float *ms)
     if (!h || !ms) return PT_ERR_INVALID;
     DeviceGuard on_device(h->device);
     if (!h->timed) return fail(h, PT_ERR_STATE, "pt_last_kernel_ms: nothing was launched yet");
+    if (h->async_series) {   // an open series of pt_run_async calls: its time so far
+        PT_HIP(h, join_async(h));
+        PT_HIP(h, hipEventRecord(h->ev_stop, h->stream));
+    }
     PT_HIP(h, hipEventSynchronize(h->ev_stop));
     PT_HIP(h, hipEventElapsedTime(ms, h->ev_start, h->ev_stop));
     return PT_OK;
@@ -1392,6 +1541,7 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
     if (x0 >= x1 || y0 >= y1 || x1 > h->camera.width || y1 > h->camera.height)
         return fail(h, PT_ERR_INVALID, "pt_debug_trace: bad rectangle [%u,%u)x[%u,%u)", x0, x1, y0, y1);
     if (iteration == 0) return fail(h, PT_ERR_INVALID, "pt_debug_trace: iterations are 1-based");
+    if (h->async_series) PT_HIP(h, join_async(h));
 
     const size_t n_pix = (size_t)(x1 - x0) * (y1 - y0);
     const size_t n_paths = n_pix * 4;

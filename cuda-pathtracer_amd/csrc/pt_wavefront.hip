@@ -613,6 +613,7 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
         const size_t pool_lds = scene_lds_bytes(p.scene, tiled) + (kBlockThreads / 64) * pool_ring(tiled) * sizeof(PoolEntry);
         uint32_t per_cu = (uint32_t)((160u * 1024u) / pool_lds);
         if (per_cu > 8u) per_cu = 8u;
+        if (p.pool_workgroups_per_cu > 0 && per_cu > (uint32_t)p.pool_workgroups_per_cu) per_cu = (uint32_t)p.pool_workgroups_per_cu;
         if (per_cu < 1u) per_cu = 1u;
         const uint32_t rows = (per_cu * (uint32_t)current_device_cus() + kWfSubQueues - 1) / kWfSubQueues;
         const uint32_t pool_chunks = p.sub_capacity / kBlockThreads;

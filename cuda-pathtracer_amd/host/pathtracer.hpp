@@ -175,6 +175,14 @@ public:
         check(pt_set_camera(handle_, &camera_->Pod()));
         check(pt_run_n(handle_, devBuffer, n, sync ? 1 : 0));
     }
+    // Run without the wait: consecutive calls overlap on the device, Wait() ends the series
+    // (pt_run_async / pt_wait).  Run itself stays blocking, as the reference's is (pathtracer.cu:241).
+    void RunAsync(float *devBuffer, uint32_t n = 1)
+    {
+        check(pt_set_camera(handle_, &camera_->Pod()));
+        check(pt_run_async(handle_, devBuffer, n));
+    }
+    void Wait() { check(pt_wait(handle_)); }
     void SaveCheckpoint(const float *devBuffer, const std::string &path) { check(pt_save_checkpoint(handle_, devBuffer, path.c_str())); }
     void LoadCheckpoint(float *devBuffer, const std::string &path) { check(pt_load_checkpoint(handle_, devBuffer, path.c_str())); }
     void SetAccel(int mode) { check(pt_set_accel(handle_, mode)); }

@@ -119,6 +119,23 @@ int pt_run(pt_handle h, float *buffer, int buffer_is_device);
  * after enqueueing on the stream. */
 int pt_run_n(pt_handle h, float *device_buffer, uint32_t n_iterations, int sync);
 
+/* The reference's frame loop calls Run once per iteration (Display, main.cpp:205-232) and Run
+ * blocks until its kernel is done (pathtracer.cu:241), so consecutive iterations can never
+ * overlap on the device.  pt_run_async is pt_run_n without the wait, and more: consecutive CALLS
+ * alternate between the library's two sets of batch buffers and two streams, the way the batches
+ * inside one pt_run_n call do, so the tail of one call's launch (its last, longest paths) runs
+ * under the next call's launch.  Results are those of pt_run / pt_run_n, bit for bit: a call's
+ * accumulation into the frame buffer waits for the accumulation of the call before it.
+ * pt_wait ends the series: it returns when every call so far has completed and the buffer holds
+ * their result.  Between pt_run_async and pt_wait the caller must not touch the buffer, also not
+ * through its own stream: part of the work runs on a stream of the library's own.  Every other
+ * entry point of this handle may be called in between (camera changes, pt_reset, a blocking
+ * pt_run, pt_read_image, ...): each of them first orders itself behind the calls made so far.
+ * Renders that do not go through the batch buffers (the megakernel variants, the NEE integrator)
+ * or do not fit half of them are simply enqueued on the handle's stream. */
+int pt_run_async(pt_handle h, float *device_buffer, uint32_t n_iterations);
+int pt_wait(pt_handle h);
+
 /* pt_run_n for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
  * results as pt_run_n, bit for bit; the call itself performs no hipMalloc / hipFree: the scratch
@@ -216,10 +233,19 @@ int pt_set_kernel_variant(pt_handle h, int variant);
  *                              memory traffic, 0.7 % slower on the 10 007-sphere scene); 1: one
  *                              launch follows every path from its camera ray on (no queue, 12
  *                              bytes; 5 % slower); -1 (default): 2, or 1 when the memory limit has no
- *                              room for one iteration's queue (kept across variant changes) */
+ *                              room for one iteration's queue (kept across variant changes)
+ *   PT_TUNE_BUFFER_SETS        path pool and wavefront launches: 0 (default): two sets of batch buffers,
+ *                              consecutive batches alternate between them on two streams and overlap;
+ *                              1: one set on the caller's stream, every launch after the one before --
+ *                              slower, but a kernel trace of it is additive (profiling; kept across
+ *                              variant changes)
+ *   PT_TUNE_POOL_WORKGROUPS    path pool: persistent workgroups per CU of a launch, 1..8 (0: the default --
+ *                              as many as fit, at most 8; calls of a pt_run_async series take fewer, so that
+ *                              two consecutive calls' launches are resident side by side; kept across
+ *                              variant changes) */
 enum { PT_TUNE_REGEN_MIN_IDLE = 0, PT_TUNE_CAMERA_RAY_RING = 1, PT_TUNE_STEAL_UNIT = 2, PT_TUNE_ITERATION_RANGES = 3,
        PT_TUNE_WAVEFRONT_REFILL = 4, PT_TUNE_BVH_NODE_STEPS = 5, PT_TUNE_BVH_STACK = 6, PT_TUNE_WAVEFRONT_BATCH = 7,
-       PT_TUNE_WAVEFRONT_WHOLE_PATHS = 8, PT_TUNE_POOL_ITERATIONS = 9 };
+       PT_TUNE_WAVEFRONT_WHOLE_PATHS = 8, PT_TUNE_POOL_ITERATIONS = 9, PT_TUNE_BUFFER_SETS = 10, PT_TUNE_POOL_WORKGROUPS = 11 };
 int pt_debug_set_tuning(pt_handle h, int key, int value);
 /* Device memory held by the instance: bytes[0] = allocated now (scene, BVH, scratch pool,
  * tickets, wavefront queues, internal frame buffer); bytes[1] = what a pt_run_n of n_iterations

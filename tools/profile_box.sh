@@ -11,6 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $REPO/bench.py --no-cpu-baseline --no-other-workloads $*"
 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- $BENCH > "$OUT/kt.log" 2>&1 || { echo "kernel-trace failed"; tail -5 "$OUT/kt.log"; exit 1; }
+# The default render overlaps the launches of consecutive batches on two streams, so the durations of
+# that trace are not additive.  A second trace with one buffer set on one stream (every launch after
+# the one before) gives per-kernel durations that sum to the step.
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_serial" -o kt -- $BENCH --serial-launches > "$OUT/kt_serial.log" 2>&1 || { echo "serial kernel-trace failed"; tail -5 "$OUT/kt_serial.log"; exit 1; }
 
 pass() {
     local name=$1; shift

@@ -23,5 +23,16 @@ for scene, depth in ((pt.SCENE_DEMO, 8), (pt.SCENE_MIXED, 16)):
                     else: tr.RunN(buf, n_per)
                 torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
             line += f"  {'path pool' if pool else 'megakernel'} {best*1e3:.1f} ms ({tr.RayCount()/best/1e9:.1f} G bounces/s)"
+        # the same launches without the wait between them: consecutive calls alternate between the two
+        # buffer sets and streams (pt_run_async), one pt_wait at the end
+        tr.SetTuning(pt.TUNE_POOL_ITERATIONS, 1024)
+        best = 1e9
+        for rep in range(3):
+            tr.Reset(); tr.ResetCounters()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for k in range(64 // n_per):
+                tr.RunAsync(buf, n_per)
+            tr.Wait(); best = min(best, time.perf_counter() - t0)
+        line += f"  path pool, asynchronous calls + one wait {best*1e3:.1f} ms ({tr.RayCount()/best/1e9:.1f} G bounces/s)"
         print(line, flush=True)
     tr.Release()
