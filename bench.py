@@ -21,7 +21,7 @@ GPU call -- and relays rank 0's JSON line.
 Either way per-GPU work is fixed as N grows (weak scaling: the job is N x iterations iterations
 of the frame).  Steps alternate between two buffers, so the reduce of step k (on RCCL's stream)
 runs while step k+1 renders; the timed region ends when every reduce has completed.  The N > 1
-line also carries `rccl_ranks_seen` (an all-reduce of ones) and `image_rmse_vs_single_rank`
+line also carries `ranks_seen` (an all-reduce of ones) with the backend that carried it and `image_rmse_vs_single_rank`
 (rank 0 re-renders a few row bands of the whole job alone and compares them with the reduced
 frame).  --workload demo4k is the 8-GPU configuration's frame (3840x2160, 128 iterations per GPU).
 
@@ -407,7 +407,9 @@ def main():
         ranks_seen = int(round(all_reduce_scalar(1.0, dist.ReduceOp.SUM)))
         names = [None] * world
         dist.all_gather_object(names, f"rank {rank}: cuda:{dev_index} {torch.cuda.get_device_name(dev_index)}")
-        multi = {"rccl_ranks_seen": ranks_seen, "backend": backend, "split": args.split, "ranks": names}
+        # ranks_seen counts the ranks of whatever backend carried the collective: RCCL only when backend is "nccl"
+        multi = {"ranks_seen": ranks_seen, "backend": backend, "collective_library": "RCCL" if backend == "nccl" else backend,
+                 "split": args.split, "ranks": names}
         if rank == 0:
             last = bufs[(step_no[0] - 1) % len(bufs)].clone()
             solo = torch.zeros_like(last)
@@ -473,7 +475,8 @@ def main():
                        "bounces_per_step_per_gpu": rays_per_launch, "spheres": int(len(sph)),
                        "parallelism": "single" if world == 1 else
                                       f"{'tile (16-row bands)' if tile_split else 'sample-range'} split x{world} + "
-                                      f"RCCL reduce(sum) overlapped with the next render",
+                                      f"{'RCCL' if backend == 'nccl' else backend + ' (rehearsal, staged through host memory)'} "
+                                      f"reduce(sum)" + (" overlapped with the next render" if backend == "nccl" else ""),
                        "kernel_variant": args.variant, "launch": launch_kernel,
                        "nearest_hit": "sphere BVH" if bvh else "linear scan", "integrator": args.integrator},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,

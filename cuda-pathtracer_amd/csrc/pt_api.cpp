@@ -854,6 +854,9 @@ static const uint64_t kWfTargetBytes = (64ull << 20) * kWfBytesPerPath;
 static int wavefront_whole_paths(const pt_context *h)
 {
     if (h->wf_dynamic_fetch <= 0 || h->accel != PT_ACCEL_AUTO || h->bvh.n_nodes == 0) return 0;
+    // the direct-light integrator carries more per path than the queue records hold (the parked term,
+    // the last BSDF pdf): its paths stay in their lanes from the camera ray on
+    if (h->integrator == PT_INTEGRATOR_NEE_MIS) return 1;
     if (h->wf_whole_paths >= 0) return h->wf_whole_paths;
     const uint64_t paths_per_it = (uint64_t)h->camera.width * h->camera.height * 4;
     if (h->memory_limit && h->memory_limit / (kWfQueueRecord + 3 * sizeof(float) + 1) < paths_per_it) return 1;
@@ -880,7 +883,7 @@ static bool takes_pool(const pt_context *h, uint64_t last_iteration, uint32_t n_
 {
     SceneParams s;
     fill_scene(h, s);
-    return h->auto_variant && h->integrator == PT_INTEGRATOR_PATH && s.bvh.n_nodes == 0 &&
+    return h->auto_variant && s.bvh.n_nodes == 0 &&
            n_iterations > 0 && n_iterations <= (uint32_t)h->pool_max_iterations &&
            last_iteration < (1u << 30) && wavefront_indexing_ok(h);
 }
@@ -1051,6 +1054,7 @@ static void fill_wavefront(const pt_context *h, WavefrontParams &p)
     p.sub_capacity = h->wf_sub_capacity;
     p.x0 = 0; p.y0 = 0; p.rect_w = p.cam.width; p.rect_h = p.cam.height;
     p.pool_workgroups_per_cu = h->pool_workgroups;
+    p.nee = h->integrator == PT_INTEGRATOR_NEE_MIS;
 }
 
 // One batch in buffer set `set` on `stream`: a launch per bounce over the compacted queues, then
@@ -1216,8 +1220,10 @@ static bool takes_wavefront(const pt_context *h, uint64_t last_iteration, uint32
 {
     if (h->wavefront) return true;
     if (takes_pool(h, last_iteration, n_iterations)) return true;
+    // (the direct-light integrator too: whole paths from the camera ray on, see wavefront_whole_paths)
     return h->auto_variant && h->accel == PT_ACCEL_AUTO && h->bvh.n_nodes > 0 &&
-           h->integrator == PT_INTEGRATOR_PATH && last_iteration < (1u << 30) && wavefront_indexing_ok(h);
+           (h->integrator == PT_INTEGRATOR_PATH || h->wf_dynamic_fetch > 0) &&
+           last_iteration < (1u << 30) && wavefront_indexing_ok(h);
 }
 
 // The handle's own scratch of the work-stealing megakernel (pool + occupancy bits in one
@@ -1565,7 +1571,7 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
     DBG_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
     // The rectangle goes through the kernels a render of this instance would use: the per-bounce
     // wavefront launches, the work-stealing megakernel, or the plain one.
-    if (takes_wavefront(h, iteration, 1) && h->integrator == PT_INTEGRATOR_PATH && iteration < (1u << 30) &&
+    if (takes_wavefront(h, iteration, 1) && (h->integrator == PT_INTEGRATOR_PATH || !h->wavefront) && iteration < (1u << 30) &&
         wavefront_indexing_ok(h)) {
         const int mode = wavefront_mode(h, 1);
         size_t counts_bytes = 0;

@@ -175,6 +175,8 @@ struct WavefrontParams {
     uint32_t sub_capacity;      // paths per sub-queue, a multiple of 256
     int whole_paths;            // BVH scenes with dynamic fetch: one launch traces whole paths (no queues)
     int path_pool;              // resident scenes: one launch of persistent waves that take camera rays from a pool (no queues)
+    int nee;                    // PT_INTEGRATOR_NEE_MIS (path pool, or whole paths from the camera ray on): a lane's pass
+                                // is a path ray or the shadow ray of the vertex it shaded in the pass before
     int pool_workgroups_per_cu; // path pool: persistent workgroups launched per CU (0: as many as fit, at most 8)
     uint32_t *counts;           // [max_bounces + 2][kWfSubQueues][kWfCountStride]: word 0 = paths alive
                                 // in sub-queue q entering bounce k, word 1 = fetch cursor of the

@@ -198,8 +198,6 @@ PT_DEV bool shade_bounce_nee(const SceneParams &sp, const SceneView &sc, float4 
         }
     }
 
-    uint32_t r[4];
-    philox4x32_10(pix, it, (uint32_t)b, STREAM_PATH, k0, k1, r);
     const float4 m = sc.mat[mat_id];
     const int2 mt = sc.mat_type[mat_id];
     const int mtype = mt.x;
@@ -258,6 +256,9 @@ PT_DEV bool shade_bounce_nee(const SceneParams &sp, const SceneView &sc, float4 
         }
     }
 
+    // the path's own random numbers only now: they hold no registers during the light sampling
+    uint32_t r[4];
+    philox4x32_10(pix, it, (uint32_t)b, STREAM_PATH, k0, k1, r);
     V3 wi;
     float pdf;
     const V3 f = sample_material(mtype, mk(m.x, m.y, m.z), m.w, __int_as_float(mt.y), wo, wi, pdf, n, u01(r[0]), u01(r[1]));

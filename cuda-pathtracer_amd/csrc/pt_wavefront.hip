@@ -12,13 +12,24 @@
 // Queue layout: 64 sub-queues, each with its own counter on its own 128-byte line, so that the
 // compaction atomics (one per wave) do not serialise on a single address.  Survivors of
 // sub-queue q stay in sub-queue q, hence no sub-queue can outgrow its capacity.
-#include "pt_trace.hpp"
+#include "pt_nee.hpp"
 
 #include <atomic>
 
 namespace ptmi {
 
 namespace {
+
+// Waves per SIMD the registers of the direct-light kernels are allocated for (measured choices).
+#ifndef PT_NEE_BVH_WAVES
+#define PT_NEE_BVH_WAVES 5   // waves per SIMD of the direct-light variant of wf_step_bvh_kernel
+#endif
+#ifndef PT_NEE_SHADOW_PASS_WAVES
+#define PT_NEE_SHADOW_PASS_WAVES 6
+#endif
+#ifndef PT_NEE_POOL_WAVES
+#define PT_NEE_POOL_WAVES 6   // waves per SIMD the direct-light pool kernel's registers are allocated for
+#endif
 
 // counts[bounce][q * kCountStride]: number of paths alive in sub-queue q entering `bounce`
 PT_DEV uint32_t *count_ptr(uint32_t *counts, int bounce, uint32_t q)
@@ -216,8 +227,12 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
 // Measured and dropped: the tree's inner nodes staged in LDS by one 1024-thread workgroup per CU
 // (4-byte stack entries, 130 KiB of LDS on the 10 007-sphere scene) -- 61.3 ms per 8 iterations
 // against 53.8 ms: four waves per SIMD instead of six cost more than the shorter fetches gain.
-template <bool WHOLE>
-__global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const WavefrontParams p)
+//
+// NEE (with WHOLE, from the camera rays on): the direct-light integrator.  The ray a lane traverses
+// is its path ray or, in the pass after a diffuse vertex parked a direct-light term, the shadow ray
+// of that vertex (`rd`, bounded by the distance to a point light).
+template <bool WHOLE, bool NEE = false>
+__global__ __launch_bounds__(kBlockThreads, NEE ? PT_NEE_BVH_WAVES : 6) void wf_step_bvh_kernel(const WavefrontParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int BT = kBlockThreads;
@@ -257,6 +272,10 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
     int best = -1;
     BvhTraversal tr;
     tr.cur = 0; tr.sp = 0; tr.visits = 0;
+    NeeState st;
+    st.shadow = false; st.end_after = false; st.specular_bounce = false; st.bsdf_pdf_prev = 0.f;
+    st.sh_d = mk(0.f, 0.f, 1.f); st.sh_tmax = PT_INF; st.sh_prim = -1; st.pending = mk(0.f, 0.f, 0.f);
+    V3 rd = d;                          // NEE: the direction being traversed (d or the shadow ray's)
 
     for (;;) {
         // ---- refill idle lanes ---------------------------------------------------------------
@@ -299,6 +318,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
                 }
                 if (has) {
                     if (WHOLE) bounce = p.bounce;
+                    if (NEE) { st.shadow = false; st.specular_bounce = false; }
                     start = true;
                 }
             }
@@ -308,10 +328,11 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
         // for the paths that continue in their lane: two call sites would run one after the other.
         if (start) {
             start = false;
-            tmax = PT_INF;
+            tmax = (NEE && st.shadow) ? st.sh_tmax : PT_INF;
             best = -1;
             over = false;
-            trav = bvh_begin(B, o, d, tmax, best, tr);
+            if (NEE) rd = st.shadow ? st.sh_d : d;
+            trav = bvh_begin(B, o, NEE ? rd : d, tmax, best, tr);
         }
 
         // ---- traverse until too few lanes are busy ---------------------------------------------
@@ -325,7 +346,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
                     if (tr.visits > B.budget) { over = trav; trav = false; }
                 }
             }
-            if (trav && tr.cur < 0) trav = bvh_leaf_step(B, stack, o, d, tmax, best, tr);
+            if (trav && tr.cur < 0) trav = bvh_leaf_step(B, stack, o, NEE ? rd : d, tmax, best, tr);
             const uint32_t busy = (uint32_t)__popcll(__ballot(trav));
             if (busy == 0 || (!exhausted && busy < (uint32_t)p.dynamic_fetch)) break;
         }
@@ -335,16 +356,32 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
         PT_LS(4);
         if (fin) PT_LS(17);
         if (fin) best = bvh_sphere_index(B, best);
-        bvh_finish_over_budget(p.scene.sph, p.scene.n_prims, fin && over, o, d, tmax, best);
+        bvh_finish_over_budget(p.scene.sph, p.scene.n_prims, fin && over, o, NEE ? rd : d, tmax, best);
         bool cont = false;
         if (fin) {
             bool end = true;
             int b = WHOLE ? bounce : p.bounce;
-            record_hit(p, n_pix, pix, it_sub, b, best);
-            if (best >= 0) {
-                end = shade_bounce(sc, p.scene.sph[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
-                bank_radiance(p, n_pix, pix, it_sub, L);
+            if (NEE && st.shadow) {
+                // the shadow query's answer: an area light is visible when the nearest hit is its own sphere,
+                // a point light when nothing lies within the segment
+                const bool visible = st.sh_prim >= 0 ? best == st.sh_prim : best < 0;
+                if (visible) L = L + st.pending;
+                st.shadow = false;
+                end = st.end_after;
+            } else {
+                record_hit(p, n_pix, pix, it_sub, b, best);
+                if (best >= 0) {
+                    if (NEE) {
+                        end = shade_bounce_nee(p.scene, sc, p.scene.sph[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b, st);
+                        if (st.shadow) { st.end_after = end; end = false; }
+                    } else {
+                        end = shade_bounce(sc, p.scene.sph[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
+                    }
+                }
             }
+            // NEE (whole paths only): the lane keeps L, emission and direct-light terms in the order they
+            // arise, and starts the path's entry with it when the path ends
+            if (!NEE || end) bank_radiance(p, n_pix, pix, it_sub, L);
             cont = !end;
             has = false;
             if (WHOLE && cont) {   // the same lane traces the path's next ray
@@ -396,9 +433,17 @@ __global__ __launch_bounds__(kBlockThreads, 6) void wf_step_bvh_kernel(const Wav
 constexpr uint32_t pool_ring(bool tiled) { return tiled ? 128u : 192u; }
 struct PoolEntry { float dx, dy, dz; uint32_t pix, it_sub; };
 
-template <bool TILED>
-__global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontParams p)
+//
+// NEE: the direct-light integrator (shade_bounce_nee).  A diffuse vertex parks its direct-light
+// term and the lane's next pass traces the shadow ray, as in render_nee_kernel; path rays and shadow
+// rays of different lanes share the scan.  Nothing else changes: the path still lives in one lane
+// from its camera ray to its end and stores its radiance once.
+// NEE_MODE: 0 the path integrator, 1 the direct-light integrator with a shadow pass, 2 with a second scan
+// (see the loop body).
+template <bool TILED, int NEE_MODE>
+__global__ __launch_bounds__(kBlockThreads, NEE_MODE == 2 ? PT_NEE_POOL_WAVES : NEE_MODE == 1 ? PT_NEE_SHADOW_PASS_WAVES : 1) void wf_pool_kernel(const WavefrontParams p)
 {
+    constexpr bool NEE = NEE_MODE != 0;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
@@ -425,6 +470,9 @@ __global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontP
     V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f), T = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
     uint32_t pix = 0, it_sub = 0;
     int b = 0;
+    NeeState st;
+    st.shadow = false; st.end_after = false; st.specular_bounce = false; st.bsdf_pdf_prev = 0.f;
+    st.sh_d = mk(0.f, 0.f, 1.f); st.sh_tmax = PT_INF; st.sh_prim = -1; st.pending = mk(0.f, 0.f, 0.f);
 
     for (;;) {
         const unsigned long long idle = __ballot(!has);
@@ -477,6 +525,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontP
                 L = mk(0.f, 0.f, 0.f);
                 pix = e.pix; it_sub = e.it_sub;
                 b = 0;
+                if (NEE) { st.shadow = false; st.specular_bounce = false; }
                 has = true;
             }
             const uint32_t taken = n_idle < count ? n_idle : count;
@@ -497,12 +546,58 @@ __global__ __launch_bounds__(kBlockThreads) void wf_pool_kernel(const WavefrontP
             int best;
             PT_LS(4);
             if (has) PT_LS(17);
-            intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, has, o, d, tmax, best);
-            bool cont = false;
+            // NEE with a shadow pass: a pass is ONE scan, which path rays and the shadow rays of the vertices
+            // shaded in the pass before share -- for scenes whose scan is what a pass costs.  NEE with a second
+            // scan: the shadow ray is traced in the pass that shaded its vertex; a lane that only waited for its
+            // shadow ray's answer would idle through the shading code of the others, which on a scene of a few
+            // spheres costs more than scanning them twice (1080p, demo scene of 9 spheres: 64.2 -> 57.7 ms per 64
+            // iterations; 71 spheres at depth 16: 57.5 -> 66.4 ms per 32).
+            constexpr bool kShadowPass = NEE_MODE == 1;
+            const bool shadow = kShadowPass && has && st.shadow;   // this pass answers the shadow query of the vertex shaded last
+            if (kShadowPass) intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, has, o, shadow ? st.sh_d : d, tmax, best, shadow ? st.sh_tmax : PT_INF);
+            else             intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, has, o, d, tmax, best);
+            bool cont = false, end = true;
+            // without a shadow pass the shadow ray's fields live inside one pass only: a pass-local copy,
+            // so that they hold no registers across the loop
+            NeeState pass_state;
+            if (NEE && !kShadowPass) {
+                pass_state.shadow = false; pass_state.end_after = false;
+                pass_state.specular_bounce = st.specular_bounce; pass_state.bsdf_pdf_prev = st.bsdf_pdf_prev;
+                pass_state.sh_d = mk(0.f, 0.f, 1.f); pass_state.sh_tmax = PT_INF; pass_state.sh_prim = -1; pass_state.pending = mk(0.f, 0.f, 0.f);
+            }
+            NeeState &ns = kShadowPass ? st : pass_state;
             if (has) {
-                bool end = true;
-                record_hit(p, n_pix, pix, it_sub, b, best);
-                if (best >= 0) end = shade_bounce(sc, (TILED ? p.scene.sph : sc.sph)[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
+                if (kShadowPass && shadow) {
+                    const bool visible = st.sh_prim >= 0 ? best == st.sh_prim : best < 0;
+                    if (visible) L = L + st.pending;
+                    st.shadow = false;
+                    end = st.end_after;
+                } else if (NEE) {
+                    record_hit(p, n_pix, pix, it_sub, b, best);
+                    if (best >= 0) {
+                        end = shade_bounce_nee(p.scene, sc, (TILED ? p.scene.sph : sc.sph)[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b, ns);
+                        if (kShadowPass && st.shadow) { st.end_after = end; end = false; }
+                    }
+                } else {
+                    record_hit(p, n_pix, pix, it_sub, b, best);
+                    if (best >= 0) end = shade_bounce(sc, (TILED ? p.scene.sph : sc.sph)[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
+                }
+            }
+            if (NEE && !kShadowPass) {
+                // the shadow rays of the vertices just shaded (o is the vertex): an area light is visible when
+                // the nearest hit is its own sphere, a point light when nothing lies within the segment
+                const bool sh = has && pass_state.shadow;
+                st.specular_bounce = pass_state.specular_bounce; st.bsdf_pdf_prev = pass_state.bsdf_pdf_prev;
+                float sh_t;
+                int sh_best;
+                intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, sh, o, pass_state.sh_d, sh_t, sh_best, pass_state.sh_tmax);
+                if (sh) {
+                    const bool visible = pass_state.sh_prim >= 0 ? sh_best == pass_state.sh_prim : sh_best < 0;
+                    if (visible) L = L + pass_state.pending;
+                }
+                continued += (unsigned long long)__popcll(__ballot(sh));   // an Intersect call like any other
+            }
+            if (has) {
                 // The path lived in this lane from its camera ray on: one store when it ends, and only
                 // if it met a light -- most paths end black, and adding their +0 changes no sum.
                 if (end && (L.x != 0.f || L.y != 0.f || L.z != 0.f || p.store_all_paths)) {
@@ -613,13 +708,20 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
         const size_t pool_lds = scene_lds_bytes(p.scene, tiled) + (kBlockThreads / 64) * pool_ring(tiled) * sizeof(PoolEntry);
         uint32_t per_cu = (uint32_t)((160u * 1024u) / pool_lds);
         if (per_cu > 8u) per_cu = 8u;
+        // the direct-light integrator's registers
+        const uint32_t nee_waves = (tiled || p.scene.n_prims > kMaxRingSpheres) ? PT_NEE_SHADOW_PASS_WAVES : PT_NEE_POOL_WAVES;
+        if (p.nee && per_cu > nee_waves) per_cu = nee_waves;
         if (p.pool_workgroups_per_cu > 0 && per_cu > (uint32_t)p.pool_workgroups_per_cu) per_cu = (uint32_t)p.pool_workgroups_per_cu;
         if (per_cu < 1u) per_cu = 1u;
         const uint32_t rows = (per_cu * (uint32_t)current_device_cus() + kWfSubQueues - 1) / kWfSubQueues;
         const uint32_t pool_chunks = p.sub_capacity / kBlockThreads;
         const dim3 pool_grid(kWfSubQueues, pool_chunks < rows ? pool_chunks : rows);
-        if (tiled) hipLaunchKernelGGL(wf_pool_kernel<true>, pool_grid, block, pool_lds, stream, p);
-        else       hipLaunchKernelGGL(wf_pool_kernel<false>, pool_grid, block, pool_lds, stream, p);
+        if (p.nee) {
+            if (tiled) hipLaunchKernelGGL((wf_pool_kernel<true, 1>), pool_grid, block, pool_lds, stream, p);
+            else if (p.scene.n_prims > kMaxRingSpheres) hipLaunchKernelGGL((wf_pool_kernel<false, 1>), pool_grid, block, pool_lds, stream, p);
+            else       hipLaunchKernelGGL((wf_pool_kernel<false, 2>), pool_grid, block, pool_lds, stream, p);
+        } else if (tiled) hipLaunchKernelGGL((wf_pool_kernel<true, 0>), pool_grid, block, pool_lds, stream, p);
+        else              hipLaunchKernelGGL((wf_pool_kernel<false, 0>), pool_grid, block, pool_lds, stream, p);
         return hipGetLastError();
     }
     const size_t lds = bvh ? bvh_stack_lds_bytes(p.scene.bvh) : scene_lds_bytes(p.scene, tiled);
@@ -629,12 +731,14 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
         // run as a second round behind the first and wait for it.
         const int n_cus = current_device_cus();
         uint32_t per_cu = (uint32_t)((160u * 1024u) / (lds ? lds : 1));
-        if (per_cu > 6u) per_cu = 6u;
+        const uint32_t by_registers = (p.whole_paths && p.nee) ? PT_NEE_BVH_WAVES : 6u;
+        if (per_cu > by_registers) per_cu = by_registers;
         if (per_cu < 1u) per_cu = 1u;
         uint32_t rows = (per_cu * (uint32_t)n_cus + kWfSubQueues - 1) / kWfSubQueues;
         const dim3 pgrid(kWfSubQueues, chunks < rows ? chunks : rows);
-        if (p.whole_paths) hipLaunchKernelGGL(wf_step_bvh_kernel<true>, pgrid, block, lds, stream, p);
-        else               hipLaunchKernelGGL(wf_step_bvh_kernel<false>, pgrid, block, lds, stream, p);
+        if (p.whole_paths && p.nee) hipLaunchKernelGGL((wf_step_bvh_kernel<true, true>), pgrid, block, lds, stream, p);
+        else if (p.whole_paths)     hipLaunchKernelGGL((wf_step_bvh_kernel<true, false>), pgrid, block, lds, stream, p);
+        else                        hipLaunchKernelGGL((wf_step_bvh_kernel<false, false>), pgrid, block, lds, stream, p);
     } else if (bvh) hipLaunchKernelGGL((wf_step_kernel<true, true>), grid, block, lds, stream, p);
     else if (tiled) hipLaunchKernelGGL((wf_step_kernel<true, false>), grid, block, lds, stream, p);
     else            hipLaunchKernelGGL((wf_step_kernel<false, false>), grid, block, lds, stream, p);

@@ -675,6 +675,30 @@ def test_config3_size_4k_tile_split_over_8_ranks(pt, torch_cuda):
     assert torch_cuda.equal(total, full)
 
 
+def test_config3_as_benchmarked_4k_128_iterations(pt, O, torch_cuda):
+    """One GPU's share of the 8-GPU configuration exactly as bench.py --workload demo4k times it:
+    demo scene, 3840x2160, depth 8, 128 iterations in ONE pt_run_n with the default variant -- the
+    path pool, 33 M paths per iteration, batches of a few iterations alternating between the two
+    buffer sets and streams some thirty times.  Two row bands (the top of the frame and one across
+    the mirror and glass balls) against the oracle, bit for bit; then the same share as rank 3 of 8
+    renders it under the sample-range split (iterations 385..512 into a sum buffer) against the
+    oracle's sum of those iterations."""
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO)
+    cam = pt.Camera(eye, look, up, 3840, 2160, 0, 0, fov)
+    tr = pt.Pathtracer(cam, 8, 1)
+    tr.Init(mats, sph, lights)
+    img = render(torch_cuda, tr, 1, 128).cpu().numpy().reshape(2160, 3840, 3)
+    assert tr.LastLaunch() == pt.LAUNCH_PATH_POOL
+    for y0, band in _oracle_bands(O, cam, mats, sph, lights, 8, 128, [(0, 1), (1500, 1)]).items():
+        assert img[y0:y0 + 1].tobytes() == band.tobytes(), y0
+    tr.SetAccumMode(pt.ACCUM_SUM)
+    img = render(torch_cuda, tr, 385, 128).cpu().numpy().reshape(2160, 3840, 3)
+    want = O.oracle_render(cam.pod, mats, sph, lights, 1, 8, first_iteration=385, n_iterations=128, rect=(0, 1501, 3840, 1502),
+                           accum_mode=O.ACCUM_SUM, n_threads=8)[0][1501:1502]
+    assert img[1501:1502].tobytes() == want.tobytes()
+    tr.Release()
+
+
 def test_config4_size_synth10k_1080p_rows_against_oracle(pt, O, torch_cuda):
     """The 10 007-sphere benchmark configuration at 1080p, one iteration with the default variant
     (sphere BVH, per-bounce wavefront launches with dynamic ray fetch) against an explicit

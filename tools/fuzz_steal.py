@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised comparison of the work-stealing megakernel (with and without iteration ranges, both
-integrators) and of PT_VARIANT_AUTO (the path pool where it applies, with random limits on the paths
-in flight) with the plain regeneration megakernel: random frame sizes, iteration counts, depths,
+integrators) and of PT_VARIANT_AUTO (the path pool and the BVH wavefront launches where they apply,
+both integrators, with random limits on the paths in flight, in one call and as a series of
+pt_run_async calls) with the plain regeneration megakernel: random frame sizes, iteration counts, depths,
 scenes (built-in ones and random sphere clouds scanned brute force or through the BVH), continued
 renders, sum buffers and row bands.  Frame buffers and Intersect-call counts must agree bit for bit.
 
@@ -54,19 +55,23 @@ def one_case(seed):
     first = int(rng.choice([1, 1, 3]))
     mode = int(rng.choice([pt.ACCUM_RUNNING_MEAN, pt.ACCUM_SUM]))
     bands = (16, int(rng.integers(0, 3)), 3) if rng.random() < 0.3 else None
-    integrator = pt.INTEGRATOR_NEE_MIS if rng.random() < 0.3 else pt.INTEGRATOR_PATH
+    integrator = pt.INTEGRATOR_NEE_MIS if rng.random() < 0.45 else pt.INTEGRATOR_PATH
     cam = pt.Camera(eye, look, up, w, h, 0, 0, fov)
     out = {}
     # + 2 / + 3: single paths / whole pixel-iterations change hands; + 10 + k: k + 1 iteration ranges
     pool_limit = int(rng.choice([0, 0, 12 * w * h * 4 * int(rng.integers(1, 4)) + 2**20]))
+    # "async": PT_VARIANT_AUTO rendered as a series of pt_run_async calls of random sizes + one pt_wait
+    chunks = []
+    while sum(chunks) < n:
+        chunks.append(min(n - sum(chunks), int(rng.choice([1, 1, 2, 3, 7, 40]))))
     for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING, pt.VARIANT_STEALING + 2, pt.VARIANT_STEALING + 3,
-                    pt.VARIANT_STEALING + 10 + int(rng.integers(1, 6)), pt.VARIANT_AUTO):
+                    pt.VARIANT_STEALING + 10 + int(rng.integers(1, 6)), pt.VARIANT_AUTO, "async"):
         tr = pt.Pathtracer(cam, depth, seed)
         tr.Init(mats, sph, lights)
         tr.SetAccel(accel)
         tr.SetIntegrator(integrator)
-        tr.SetKernelVariant(variant)
-        if variant == pt.VARIANT_AUTO:
+        tr.SetKernelVariant(pt.VARIANT_AUTO if variant == "async" else variant)
+        if variant in (pt.VARIANT_AUTO, "async"):
             tr.SetMemoryLimit(pool_limit)
         tr.SetAccumMode(mode)
         if bands:
@@ -76,7 +81,12 @@ def one_case(seed):
         if first > 1:
             tr.RunN(buf, first - 1)
         tr.ResetCounters()
-        tr.RunN(buf, n)
+        if variant == "async":
+            for k in chunks:
+                tr.RunAsync(buf, k)
+            tr.Wait()
+        else:
+            tr.RunN(buf, n)
         torch.cuda.synchronize()
         out[variant] = (buf.cpu().numpy().tobytes(), tr.RayCount())
         tr.Release()

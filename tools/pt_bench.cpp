@@ -14,11 +14,12 @@
 // The shorthand codes of the tuning experiments (a variant plus one pt_debug_set_tuning call):
 // 2..64 regeneration threshold, 300 / 301 camera-ray ring off / on, 500 + 1 stealing without the
 // ring, + 2 / + 3 unit of 1 / 4 paths, + 10 + k: k + 1 iteration ranges, 100 + 1 static wavefront,
-// 100 + k refill threshold k.
+// 100 + k refill threshold k, 999 PT_VARIANT_AUTO.
 static int set_variant(pt_handle h, int v)
 {
     int base = v, key = -1, value = 0;
-    if (v >= 2 && v <= 64) { base = PT_VARIANT_REGENERATION; key = PT_TUNE_REGEN_MIN_IDLE; value = v; }
+    if (v == 999) base = PT_VARIANT_AUTO;   // so that -1 can be combined with + 1000 / + 2000: 1999, 2999
+    else if (v >= 2 && v <= 64) { base = PT_VARIANT_REGENERATION; key = PT_TUNE_REGEN_MIN_IDLE; value = v; }
     else if (v == 300 || v == 301) { base = PT_VARIANT_REGENERATION; key = PT_TUNE_CAMERA_RAY_RING; value = v - 300; }
     else if (v > PT_VARIANT_WAVEFRONT && v <= PT_VARIANT_WAVEFRONT + 64) { base = PT_VARIANT_WAVEFRONT; key = PT_TUNE_WAVEFRONT_REFILL; value = v - 100 == 1 ? 0 : v - 100; }
     else if (v == PT_VARIANT_STEALING + 1) { base = PT_VARIANT_STEALING; key = PT_TUNE_CAMERA_RAY_RING; value = 0; }
