@@ -1686,7 +1686,7 @@ int pt_selftest_exhaustive(pt_handle h, int op, uint64_t *mismatches)
 {
     if (!h || !mismatches) return PT_ERR_INVALID;
     DeviceGuard on_device(h->device);
-    if (op < 0 || op > 2) return fail(h, PT_ERR_INVALID, "pt_selftest_exhaustive: op must be 0, 1 or 2");
+    if (op < 0 || op > 3) return fail(h, PT_ERR_INVALID, "pt_selftest_exhaustive: op must be 0, 1, 2 or 3");
     unsigned long long *d = nullptr, v = 0;
     int rc = PT_OK;
     hipError_t e = hipSuccess;

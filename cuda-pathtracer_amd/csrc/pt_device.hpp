@@ -49,18 +49,34 @@ PT_DEV bool in_exp_range(float x, uint32_t lo_biased, uint32_t hi_biased)
     return ((__float_as_uint(x) & 0x7fffffffu) - (lo_biased << 23)) < ((hi_biased - lo_biased) << 23);
 }
 
+PT_DEV float sqrt_newton(float x)
+{
+    const float r = __builtin_amdgcn_rsqf(x);
+    float g = x * r, h = 0.5f * r;
+    const float e = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, e, g);
+    h = __builtin_fmaf(h, e, h);
+    const float d = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(d, h, g);
+}
+
 PT_DEV float pt_sqrt(float x)
 {
     // positive, 2^-100 <= x < 2^100 (a set sign bit makes the unsigned difference huge)
-    if (__builtin_expect((__float_as_uint(x) - (27u << 23)) < (200u << 23), 1)) {
-        const float r = __builtin_amdgcn_rsqf(x);
-        float g = x * r, h = 0.5f * r;
-        const float e = __builtin_fmaf(-h, g, 0.5f);
-        g = __builtin_fmaf(g, e, g);
-        h = __builtin_fmaf(h, e, h);
-        const float d = __builtin_fmaf(-g, g, x);
-        return __builtin_fmaf(d, h, g);
-    }
+    if (__builtin_expect((__float_as_uint(x) - (27u << 23)) < (200u << 23), 1)) return sqrt_newton(x);
+    return __builtin_sqrtf(x);
+}
+
+// pt_sqrt for the discriminant of a sphere test, where the root only feeds t = b -+ root and the
+// test eps < t < tmax with a finite tmax (primitive.h:43-44, scene.h:78-80).  The short sequence is
+// correctly rounded for every finite x >= 2^-100 (measured: it loses bits below 2^-102, where its
+// residual turns denormal, and nowhere above), so ONE comparison gates it; what the comparison
+// lets through besides is +infinity, for which the sequence returns NaN instead of +infinity -- and
+// both make t infinite or NaN, which fails the test either way.  (NaN and everything below 2^-100,
+// zero and the negative numbers included, compare false and take the generic expansion.)
+PT_DEV float pt_sqrt_discriminant(float x)
+{
+    if (__builtin_expect(x > 7.8886090522101181e-31f, 1)) return sqrt_newton(x);   // 2^-100
     return __builtin_sqrtf(x);
 }
 
@@ -117,7 +133,21 @@ PT_DEV V3 cross(V3 a, V3 b)                                                     
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 PT_DEV float length(V3 a) { return pt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
-PT_DEV V3 normalize(V3 a) { return vdiv(a, length(a)); }                         // geometry.h:131-133
+// geometry.h:131-133: a * (1.f / Length()).  One range test serves the square root and the
+// reciprocal: for 2^-100 <= |a|^2 < 2^100 the length lies in [2^-50, 2^50), inside the reciprocal's
+// fast range; outside, both take their generic expansions -- the same correctly rounded values as
+// pt_rcp(pt_sqrt(.)) returns, whichever of their paths those would have taken.
+PT_DEV V3 normalize(V3 a)
+{
+    const float len2 = a.x * a.x + a.y * a.y + a.z * a.z;
+    float inv;
+    if (__builtin_expect((__float_as_uint(len2) - (27u << 23)) < (200u << 23), 1)) {
+        inv = rcp_newton(sqrt_newton(len2));
+    } else {
+        inv = 1.f / __builtin_sqrtf(len2);
+    }
+    return a * inv;
+}
 
 // ---- counter-based RNG --------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11).  ctr = (pixel, iteration, slot, stream), key = seed.
@@ -360,7 +390,7 @@ PT_DEV void sphere_test(float4 s, int index, V3 o, V3 d, float &tmax, int &best)
     PT_LS(2);
     if (!(det < 0.f)) {
         PT_LS(3);
-        const float sq = pt_sqrt(det);
+        const float sq = pt_sqrt_discriminant(det);
         float t = b - sq;
         if (!(t > PT_EPSILON)) t = b + sq;
         if (t > PT_EPSILON && t < tmax) { tmax = t; best = index; }

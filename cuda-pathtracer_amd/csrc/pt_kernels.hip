@@ -586,7 +586,8 @@ __global__ void selftest_material_kernel(int type, float4 color_coef, float inv_
 }
 
 // Compares the short sequences with the compiler's generic IEEE expansions: every one of the
-// 2^32 bit patterns for sqrt and 1/x, 2^32 Philox-random operand pairs for a/b.
+// 2^32 bit patterns for sqrt (op 0; op 3: the sphere test's variant) and 1/x, 2^32 Philox-random
+// operand pairs for a/b.
 __global__ void selftest_exhaustive_kernel(int op, unsigned long long *mismatches)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // grid covers 2^24 threads
@@ -596,6 +597,12 @@ __global__ void selftest_exhaustive_kernel(int op, unsigned long long *mismatche
         float got, want;
         if (op == 0) { const float x = __uint_as_float(bits); got = pt_sqrt(x); want = __builtin_sqrtf(x); }
         else if (op == 1) { const float x = __uint_as_float(bits); got = pt_rcp(x); want = 1.f / x; }
+        else if (op == 3) {
+            // the sphere test's variant: everything but +infinity (there: NaN or +infinity, no finite value)
+            const float x = __uint_as_float(bits);
+            got = pt_sqrt_discriminant(x); want = __builtin_sqrtf(x);
+            if (bits == 0x7f800000u) got = (got != got || got == want) ? want : 0.f;
+        }
         else {
             uint32_t r[4];
             philox4x32_10(bits, 0u, 0u, 0x5e1f7e57u, 1u, 2u, r);

@@ -72,6 +72,27 @@ PT_DEV SceneView stage_scene(const SceneParams &p, unsigned char *lds_raw, int t
 // Scan `count` spheres that sit in LDS starting at global index `base` (index order).
 PT_DEV void scan_lds(const float4 *sph, int base, int count, V3 o, V3 d, float &tmax, int &best)
 {
+    // Scenes of up to 16 spheres (the demo scene has 9): the same groups of four, unrolled, so that a
+    // sphere's index is an immediate of the select that records the hit instead of a register that has
+    // to be loaded from a loop counter first, and the loop's own counting goes away.
+    if (base == 0 && count <= 16) {
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+            if (g + 4 <= count) {
+                const float4 s0 = sph[g], s1 = sph[g + 1], s2 = sph[g + 2], s3 = sph[g + 3];
+                sphere_test(s0, g, o, d, tmax, best);
+                sphere_test(s1, g + 1, o, d, tmax, best);
+                sphere_test(s2, g + 2, o, d, tmax, best);
+                sphere_test(s3, g + 3, o, d, tmax, best);
+            } else {
+                if (g < count) sphere_test(sph[g], g, o, d, tmax, best);
+                if (g + 1 < count) sphere_test(sph[g + 1], g + 1, o, d, tmax, best);
+                if (g + 2 < count) sphere_test(sph[g + 2], g + 2, o, d, tmax, best);
+                break;
+            }
+        }
+        return;
+    }
     int i = 0;
     for (; i + 4 <= count; i += 4) {
         const float4 s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
@@ -87,7 +108,7 @@ PT_DEV void scan_lds(const float4 *sph, int base, int count, V3 o, V3 d, float &
 PT_DEV void sphere_accept(float b, float det, int index, float &tmax, int &best)
 {
     if (!(det < 0.f)) {
-        const float sq = pt_sqrt(det);
+        const float sq = pt_sqrt_discriminant(det);
         float t = b - sq;
         if (!(t > PT_EPSILON)) t = b + sq;
         if (t > PT_EPSILON && t < tmax) { tmax = t; best = index; }
@@ -133,7 +154,7 @@ PT_DEV void sphere_test_lex(float4 s, int index, V3 o, V3 d, float &tmax, int &b
     const float b = opx * d.x + opy * d.y + opz * d.z;
     const float det = b * b - (opx * opx + opy * opy + opz * opz) + s.w;
     if (!(det < 0.f)) {
-        const float sq = pt_sqrt(det);
+        const float sq = pt_sqrt_discriminant(det);
         float t = b - sq;
         if (!(t > PT_EPSILON)) t = b + sq;
         if (t > PT_EPSILON && (t < tmax || (t == tmax && best >= 0 && index < best))) { tmax = t; best = index; }
@@ -393,7 +414,7 @@ PT_DEV void sphere_test_slot(const BvhParams &B, float4 s, int slot, V3 o, V3 d,
     const float b = opx * d.x + opy * d.y + opz * d.z;
     const float det = b * b - (opx * opx + opy * opy + opz * opz) + s.w;
     if (!(det < 0.f)) {
-        const float sq = pt_sqrt(det);
+        const float sq = pt_sqrt_discriminant(det);
         float t = b - sq;
         if (!(t > PT_EPSILON)) t = b + sq;
         if (t > PT_EPSILON) {

@@ -362,7 +362,8 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
  * pt_selftest_eval: out[i] = op(a[i], b[i]) on the device; op 0 sqrt(a), 1 1/a, 2 a/b,
  *   3 sin(a), 4 cos(a) (b may be NULL unless op == 2).  Host pointers.
  * pt_selftest_exhaustive: number of results that differ from the compiler's generic IEEE
- *   expansion over all 2^32 float bit patterns (op 0, 1) or 2^32 random operand pairs (op 2). */
+ *   expansion over all 2^32 float bit patterns (op 0, 1; op 3: the square root of the sphere
+ *   test's discriminant, which may return NaN for +infinity) or 2^32 random operand pairs (op 2). */
 int pt_selftest_eval(pt_handle h, int op, const float *a, const float *b, float *out, uint64_t n);
 int pt_selftest_exhaustive(pt_handle h, int op, uint64_t *mismatches);
 /* SampleMaterial (scene.h:177-221) as the kernels evaluate it, row by row on the device: in

@@ -56,9 +56,11 @@ def test_sqrt_rcp_div_match_numpy_bitwise(tracer):
         assert same_bits(tracer.SelftestEval(2, num, den), num / den)
 
 
-@pytest.mark.parametrize("op", [0, 1, 2])
+@pytest.mark.parametrize("op", [0, 1, 2, 3])
 def test_short_sequences_equal_ieee_expansion_exhaustively(tracer, op):
-    """All 2^32 bit patterns (sqrt, 1/x) and 2^32 random pairs (a/b), compared on the device."""
+    """All 2^32 bit patterns (sqrt, 1/x, and 3: the sphere test's square root, whose one-comparison
+    gate may let +infinity through to the short sequence, where NaN is as good as +infinity) and 2^32
+    random pairs (a/b), compared on the device."""
     assert tracer.SelftestExhaustive(op) == 0
 
 
