@@ -18,7 +18,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptmi.so")
+# PTMI_LIBRARY: another build of the same library (measurement builds of the tools); there is no fallback either way
+LIB_PATH = os.environ.get("PTMI_LIBRARY") or os.path.join(_HERE, "libptmi.so")
 
 # ---- POD layouts of include/ptmi.h -------------------------------------------------------------
 CAMERA_DTYPE = np.dtype([("pos", "<f4", 3), ("px_x", "<f4", 3), ("px_y", "<f4", 3),

@@ -19,6 +19,14 @@
 
 using namespace ptmi;
 
+#ifdef PT_SORT_EXPERIMENT
+namespace ptmi {
+hipError_t sort_queue_experiment(const WavefrontParams &p, WavefrontQueue from, WavefrontQueue to, const uint32_t *counts, int mode,
+                                 hipStream_t stream);
+}
+#include <cstdlib>
+#endif
+
 struct pt_context {
     pt_camera_pod camera;
     int max_bounces;
@@ -1076,13 +1084,29 @@ static int launch_wavefront_batch(pt_context *h, WavefrontParams &p, int mode, s
         PT_HIP(h, hipMemsetAsync(pipe.radiance, 0, batch_paths * 3 * sizeof(float), stream));
     }
     const int last = mode == 1 || mode == 3 ? 0 : mode == 2 ? (h->max_bounces < 1 ? h->max_bounces : 1) : h->max_bounces;
+#ifdef PT_SORT_EXPERIMENT
+    // measurement build: the survivors of every bounce are sorted inside their sub-queues before the next launch
+    const char *sort_env = getenv("PT_EXPERIMENT_SORT");
+    const int sort_mode = sort_env ? atoi(sort_env) : 0;
+    int flip = 0;
+#endif
     for (int b = 0; b <= last; ++b) {
         p.bounce = b;
         p.whole_paths = mode == 1 || (mode == 2 && b == 1);
         p.path_pool = mode == 3;
         p.out = pipe.queue[b & 1];          // not written by a whole-path launch
         p.in = pipe.queue[(b & 1) ^ 1];
+#ifdef PT_SORT_EXPERIMENT
+        if (flip) { p.out = pipe.queue[(b & 1) ^ 1]; p.in = pipe.queue[b & 1]; }
+#endif
         PT_HIP(h, launch_wavefront_step(p, tiled, stream));
+#ifdef PT_SORT_EXPERIMENT
+        if (sort_mode > 0 && b < last && (mode == 0 || mode == 2) && p.scene.bvh.n_nodes) {
+            const uint32_t *next_counts = pipe.counts + (size_t)(b + 1) * kWfSubQueues * kWfCountStride;
+            PT_HIP(h, sort_queue_experiment(p, p.out, p.in, next_counts, sort_mode, stream));
+            flip ^= 1;
+        }
+#endif
     }
     if (after) PT_HIP(h, hipStreamWaitEvent(stream, after, 0));
     PT_HIP(h, launch_wavefront_resolve(p, stream));
