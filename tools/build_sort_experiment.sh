@@ -7,4 +7,4 @@ mkdir -p tools/ab_sort
     -fhip-fp32-correctly-rounded-divide-sqrt -Iinclude -Icuda-pathtracer_amd/csrc -Wall -Wno-unused-function -DPT_SORT_EXPERIMENT \
     -shared -o tools/ab_sort/libptmi.so cuda-pathtracer_amd/csrc/pt_kernels.hip cuda-pathtracer_amd/csrc/pt_wavefront.hip \
     cuda-pathtracer_amd/csrc/pt_nee.hip cuda-pathtracer_amd/csrc/pt_api.cpp cuda-pathtracer_amd/csrc/pt_scene.cpp \
-    cuda-pathtracer_amd/csrc/pt_bvh.cpp cuda-pathtracer_amd/csrc/pt_checkpoint.cpp cuda-pathtracer_amd/csrc/pt_sort_experiment.hip
+    cuda-pathtracer_amd/csrc/pt_bvh.cpp cuda-pathtracer_amd/csrc/pt_checkpoint.cpp tools/experiments/pt_sort_experiment.hip
