@@ -34,6 +34,11 @@ CAMERA_STATE_DTYPE = np.dtype([("view", "<f4", (3, 3)), ("dist", "<f4"), ("hfov"
 assert CAMERA_STATE_DTYPE.itemsize == 104
 assert CAMERA_DTYPE.itemsize == 56 and MATERIAL_DTYPE.itemsize == 20
 assert SPHERE_DTYPE.itemsize == 24 and LIGHT_DTYPE.itemsize == 28
+# pt_triangle: this build's extension (the reference has spheres only, primitive.h:25-28); triangle k is
+# primitive len(spheres) + k
+TRIANGLE_DTYPE = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3), ("material_id", "<u4"),
+                           ("light_id", "<i4")])
+assert TRIANGLE_DTYPE.itemsize == 44
 
 DIFFUSE, SPECULAR, TRANSMISSIVE = 0, 1, 2
 POINT_LIGHT, AREA_LIGHT = 0, 1
@@ -56,6 +61,7 @@ _pu32, _pu64, _pf = ctypes.POINTER(_u32), ctypes.POINTER(_u64), ctypes.POINTER(c
 ABI = [
     ("pt_create", _i32, [ctypes.POINTER(_vp), _vp, _i32, _u64]),
     ("pt_init_scene", _i32, [_vp, _vp, _u32, _vp, _u32, _vp, _u32]),
+    ("pt_init_scene_triangles", _i32, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u32]),
     ("pt_destroy", _i32, [_vp]),
     ("pt_last_error", ctypes.c_char_p, [_vp]),
     ("pt_run", _i32, [_vp, _vp, _i32]),
@@ -294,11 +300,18 @@ class Pathtracer:
             raise PtError(rc, self._lib.pt_last_error(self._h).decode())
 
     # -- the reference's five methods -----------------------------------------------------------
-    def Init(self, materials, primitives, lights) -> bool:
+    def Init(self, materials, primitives, lights, triangles=None) -> bool:
+        """``triangles`` (TRIANGLE_DTYPE records, optional): this build's extension, primitives behind the
+        spheres; such scenes render through the path pool with the path integrator only."""
         m = np.ascontiguousarray(materials, MATERIAL_DTYPE)
         p = np.ascontiguousarray(primitives, SPHERE_DTYPE)
         l = np.ascontiguousarray(lights, LIGHT_DTYPE)
-        self._check(self._lib.pt_init_scene(self._h, _ptr(m), len(m), _ptr(p), len(p), _ptr(l), len(l)))
+        if triangles is None or len(triangles) == 0:
+            self._check(self._lib.pt_init_scene(self._h, _ptr(m), len(m), _ptr(p), len(p), _ptr(l), len(l)))
+        else:
+            t = np.ascontiguousarray(triangles, TRIANGLE_DTYPE)
+            self._check(self._lib.pt_init_scene_triangles(self._h, _ptr(m), len(m), _ptr(p), len(p), _ptr(t), len(t),
+                                                          _ptr(l), len(l)))
         return True
 
     def Run(self, dev_buffer) -> None:

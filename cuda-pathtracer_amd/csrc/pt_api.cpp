@@ -41,6 +41,8 @@ struct pt_context {
     int device;
     // scene (device)
     float4 *d_sph, *d_aux, *d_mat, *d_light, *d_light_geom;
+    float4 *d_tri;        // triangles, four float4 each (pt_init_scene_triangles); NULL when the scene has none
+    uint32_t n_tris;
     int2 *d_mat_type;   // (type, bits of 1.f / coef)
     int integrator;       // PT_INTEGRATOR_*
     uint32_t n_prims, n_mats, n_lights;
@@ -156,7 +158,7 @@ static hipError_t join_async(pt_context *h)
 // otherwise spheres stream through an LDS tile and the rest is read from device memory.
 static bool scene_streams(const SceneParams &s)
 {
-    return s.n_prims > kMaxResidentSpheres || scene_lds_bytes(s, false) > kMaxResidentBytes;
+    return s.n_prims > kMaxResidentSpheres || s.n_tris > kMaxResidentTriangles || scene_lds_bytes(s, false) > kMaxResidentBytes;
 }
 
 static bool camera_ok(const pt_camera_pod *c)
@@ -206,6 +208,8 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
     h->device = dev;
     h->d_sph = h->d_aux = h->d_mat = h->d_light = h->d_light_geom = nullptr;
     h->d_mat_type = nullptr;
+    h->d_tri = nullptr;
+    h->n_tris = 0;
     h->integrator = PT_INTEGRATOR_PATH;
     h->n_prims = h->n_mats = h->n_lights = 0;
     h->scene_ready = false;
@@ -270,6 +274,9 @@ static void free_scene(pt_context *h)
     if (h->d_light) (void)hipFree(h->d_light);
     if (h->d_mat_type) (void)hipFree(h->d_mat_type);
     if (h->d_light_geom) (void)hipFree(h->d_light_geom);
+    if (h->d_tri) (void)hipFree(h->d_tri);
+    h->d_tri = nullptr;
+    h->n_tris = 0;
     h->d_sph = h->d_aux = h->d_mat = h->d_light = h->d_light_geom = nullptr;
     h->d_mat_type = nullptr;
     if (h->d_bvh) (void)hipFree(h->d_bvh);
@@ -406,11 +413,48 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
                   const pt_sphere *spheres, uint32_t n_spheres,
                   const pt_light *lights, uint32_t n_lights)
 {
+    return pt_init_scene_triangles(h, materials, n_materials, spheres, n_spheres, nullptr, 0, lights, n_lights);
+}
+
+// Device form of a triangle: (v0, material id), (v1 - v0, light id), (v2 - v0, -), (unit normal, -).  The edges
+// are the single subtractions the intersection test starts with, the normal is normalize(e1 x e2) evaluated
+// like the reference's Vec::Cross / Normalize (geometry.h:45-47,131-133: a * (1.f / Length())) -- this file is
+// compiled without contraction, sqrtf and '/' are IEEE -- so hoisting them to the host changes no bit.
+static void triangle_entry(const pt_triangle &t, float4 out[4])
+{
+    const float e1[3] = {t.v1[0] - t.v0[0], t.v1[1] - t.v0[1], t.v1[2] - t.v0[2]};
+    const float e2[3] = {t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2]};
+    const float c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const float len = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    const float inv = 1.f / len;
+    float mbits, lbits;
+    memcpy(&mbits, &t.material_id, 4);
+    memcpy(&lbits, &t.light_id, 4);
+    out[0] = make_float4(t.v0[0], t.v0[1], t.v0[2], mbits);
+    out[1] = make_float4(e1[0], e1[1], e1[2], lbits);
+    out[2] = make_float4(e2[0], e2[1], e2[2], 0.f);
+    out[3] = make_float4(c[0] * inv, c[1] * inv, c[2] * inv, 0.f);
+}
+
+int pt_init_scene_triangles(pt_handle h, const pt_material *materials, uint32_t n_materials,
+                            const pt_sphere *spheres, uint32_t n_spheres,
+                            const pt_triangle *triangles, uint32_t n_triangles,
+                            const pt_light *lights, uint32_t n_lights)
+{
     if (!h) return PT_ERR_INVALID;
     DeviceGuard on_device(h->device);
-    if ((n_materials && !materials) || (n_spheres && !spheres) || (n_lights && !lights))
+    if ((n_materials && !materials) || (n_spheres && !spheres) || (n_lights && !lights) || (n_triangles && !triangles))
         return fail(h, PT_ERR_INVALID, "pt_init_scene: NULL array with non-zero count");
-    if (n_spheres > 0x7fffffffu / 2) return fail(h, PT_ERR_INVALID, "pt_init_scene: too many spheres");
+    if (n_spheres > 0x7fffffffu / 2 || n_triangles > 0x7fffffffu / 2 - n_spheres)
+        return fail(h, PT_ERR_INVALID, "pt_init_scene: too many primitives");
+    for (uint32_t i = 0; i < n_triangles; ++i) {
+        if (triangles[i].material_id >= n_materials)
+            return fail(h, PT_ERR_INVALID, "pt_init_scene: triangle %u references material %u of %u", i,
+                        triangles[i].material_id, n_materials);
+        if (triangles[i].light_id >= (int32_t)n_lights)
+            return fail(h, PT_ERR_INVALID, "pt_init_scene: triangle %u references light %d of %u", i,
+                        triangles[i].light_id, n_lights);
+    }
     for (uint32_t i = 0; i < n_spheres; ++i) {
         if (spheres[i].material_id >= n_materials)
             return fail(h, PT_ERR_INVALID, "pt_init_scene: sphere %u references material %u of %u", i,
@@ -420,9 +464,9 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
                         spheres[i].light_id, n_lights);
     }
     for (uint32_t i = 0; i < n_lights; ++i)
-        if (lights[i].type == PT_AREA_LIGHT && lights[i].u.prim_id >= n_spheres)
-            return fail(h, PT_ERR_INVALID, "pt_init_scene: light %u sits on sphere %u of %u", i, lights[i].u.prim_id,
-                        n_spheres);
+        if (lights[i].type == PT_AREA_LIGHT && lights[i].u.prim_id >= n_spheres + n_triangles)
+            return fail(h, PT_ERR_INVALID, "pt_init_scene: light %u sits on primitive %u of %u", i, lights[i].u.prim_id,
+                        n_spheres + n_triangles);
     if (h->async_series) PT_HIP(h, join_async(h));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     free_scene(h);
@@ -472,20 +516,25 @@ int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_material
     if (ue == hipSuccess) ue = upload(&h->d_light, light);
     if (ue == hipSuccess) ue = upload(&h->d_mat_type, mtype);
     if (ue == hipSuccess) ue = upload(&h->d_light_geom, light_geom);
+    std::vector<float4> tri((size_t)n_triangles * 4);
+    for (uint32_t i = 0; i < n_triangles; ++i) triangle_entry(triangles[i], &tri[(size_t)i * 4]);
+    if (ue == hipSuccess && n_triangles) ue = upload(&h->d_tri, tri);
     if (ue != hipSuccess) {
         free_scene(h);
         return fail(h, ue == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_DEVICE, "pt_init_scene: scene upload failed: %s",
                     hipGetErrorString(ue));
     }
     h->n_prims = n_spheres; h->n_mats = n_materials; h->n_lights = n_lights;
-    h->scene_bytes = (sph.size() + aux.size() + mat.size() + light.size() + light_geom.size()) * sizeof(float4) +
+    h->n_tris = n_triangles;
+    h->scene_bytes = (sph.size() + aux.size() + mat.size() + light.size() + light_geom.size() + tri.size()) * sizeof(float4) +
                      mtype.size() * sizeof(int);
-    if (n_spheres > kBvhMinSpheres) {
+    if (n_spheres > kBvhMinSpheres && n_triangles == 0) {   // scenes with triangles are rendered by the linear scan
         const int rc = upload_bvh(h, sph, spheres, n_spheres);
         if (rc != PT_OK) { free_scene(h); return rc; }
     }
     // fingerprint for checkpoints; of a light only the union member its type selects counts
     h->scene_hash = fingerprint(spheres, n_spheres * sizeof(pt_sphere), fingerprint(materials, n_materials * sizeof(pt_material)));
+    if (n_triangles) h->scene_hash = fingerprint(triangles, n_triangles * sizeof(pt_triangle), h->scene_hash);
     for (uint32_t i = 0; i < n_lights; ++i) {
         h->scene_hash = fingerprint(&lights[i].type, sizeof lights[i].type, h->scene_hash);
         if (lights[i].type == PT_POINT_LIGHT) h->scene_hash = fingerprint(lights[i].u.pos, sizeof lights[i].u.pos, h->scene_hash);
@@ -819,6 +868,7 @@ static void fill_scene(const pt_context *h, SceneParams &s)
     s.sph = h->d_sph; s.aux = h->d_aux; s.mat = h->d_mat; s.mat_type = h->d_mat_type; s.light = h->d_light;
     s.light_geom = h->d_light_geom;
     s.n_prims = h->n_prims; s.n_mats = h->n_mats; s.n_lights = h->n_lights;
+    s.tri = h->d_tri; s.n_tris = h->n_tris;
     if (h->accel == PT_ACCEL_AUTO) s.bvh = h->bvh;
     else memset(&s.bvh, 0, sizeof s.bvh);
 }
@@ -891,7 +941,7 @@ static bool takes_pool(const pt_context *h, uint64_t last_iteration, uint32_t n_
 {
     SceneParams s;
     fill_scene(h, s);
-    return h->auto_variant && s.bvh.n_nodes == 0 &&
+    return h->auto_variant && s.bvh.n_nodes == 0 && (h->n_tris == 0 || h->integrator == PT_INTEGRATOR_PATH) &&
            n_iterations > 0 && n_iterations <= (uint32_t)h->pool_max_iterations &&
            last_iteration < (1u << 30) && wavefront_indexing_ok(h);
 }
@@ -1367,6 +1417,17 @@ static int enqueue_megakernel(pt_context *h, float *dbuf, uint32_t n_iterations,
     return PT_OK;
 }
 
+// Scenes with triangles go through the path pool or not at all.
+static int triangles_renderable(pt_context *h, uint64_t last_iteration, uint32_t n_iterations)
+{
+    if (h->integrator != PT_INTEGRATOR_PATH)
+        return fail(h, PT_ERR_STATE, "scenes with triangles: the NEE integrator samples sphere lights only (primitive.h:50-72)");
+    if (h->wavefront || !takes_pool(h, last_iteration, n_iterations))
+        return fail(h, PT_ERR_STATE, "scenes with triangles are rendered by the path pool only: PT_VARIANT_AUTO, "
+                                     "PT_TUNE_POOL_ITERATIONS at its default, frames of fewer than 2^20 rows");
+    return PT_OK;
+}
+
 // Enqueue n iterations on the handle's stream (async_call: see enqueue_wavefront).
 static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations, bool async_call = false)
 {
@@ -1378,6 +1439,11 @@ static int enqueue(pt_context *h, float *dbuf, uint32_t n_iterations, bool async
         return fail(h, PT_ERR_STATE, "the wavefront variant only implements PT_INTEGRATOR_PATH");
     if (h->wavefront && !wavefront_indexing_ok(h))
         return fail(h, PT_ERR_INVALID, "the wavefront variant takes frames of fewer than 2^20 rows and band_rows * world below 2^30");
+    if (h->n_tris) {   // triangles: the path pool's kernels only
+        const int rc = triangles_renderable(h, h->iteration + (uint64_t)n_iterations, n_iterations);
+        if (rc != PT_OK) return rc;
+        return enqueue_wavefront(h, dbuf, n_iterations, async_call);
+    }
     if (takes_wavefront(h, h->iteration + (uint64_t)n_iterations, n_iterations)) {
         const int rc = enqueue_wavefront(h, dbuf, n_iterations, async_call);
         // PT_VARIANT_AUTO: when the queues cannot be had the megakernel renders the same image
@@ -1425,6 +1491,8 @@ int pt_run_n_noalloc(pt_handle h, float *device_buffer, uint32_t n_iterations, i
     if (h->wavefront)
         return fail(h, PT_ERR_STATE, "pt_run_n_noalloc: the wavefront variant needs queues that grow with the frame; "
                                      "select PT_VARIANT_AUTO or a megakernel variant");
+    if (h->n_tris)
+        return fail(h, PT_ERR_STATE, "pt_run_n_noalloc: scenes with triangles are rendered by the path pool, whose buffers grow with the frame");
     const uint64_t tiles = (uint64_t)div_up(h->camera.width, 16) * div_up(h->camera.height, 16);
     if (tiles + 1 > h->fixed_scratch.ticket_words)
         return fail(h, PT_ERR_INVALID, "pt_run_n_noalloc: %ux%u is %llu tiles of 16x16 pixels, the static scratch "
@@ -1571,6 +1639,10 @@ int pt_debug_trace(pt_handle h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t 
     if (x0 >= x1 || y0 >= y1 || x1 > h->camera.width || y1 > h->camera.height)
         return fail(h, PT_ERR_INVALID, "pt_debug_trace: bad rectangle [%u,%u)x[%u,%u)", x0, x1, y0, y1);
     if (iteration == 0) return fail(h, PT_ERR_INVALID, "pt_debug_trace: iterations are 1-based");
+    if (h->n_tris) {
+        const int trc = triangles_renderable(h, iteration, 1);
+        if (trc != PT_OK) return trc;
+    }
     if (h->async_series) PT_HIP(h, join_async(h));
 
     const size_t n_pix = (size_t)(x1 - x0) * (y1 - y0);

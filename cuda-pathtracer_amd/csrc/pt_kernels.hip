@@ -696,7 +696,7 @@ size_t scene_lds_bytes(const SceneParams &s, bool tiled)
 {
     if (tiled) return (size_t)kTileSpheres * sizeof(float4);
     const size_t n = (size_t)s.n_prims * 2 * sizeof(float4) + (size_t)s.n_mats * (sizeof(float4) + sizeof(int2)) +
-                     (size_t)s.n_lights * sizeof(float4);
+                     (size_t)s.n_lights * sizeof(float4) + (size_t)s.n_tris * 4 * sizeof(float4);
     return (n + 15) & ~(size_t)15;
 }
 

@@ -12,6 +12,9 @@ constexpr uint32_t kTileSpheres = 1024;
 // Scenes up to this many spheres are staged in LDS once per workgroup
 // (32 B per sphere -> 16 KiB at the limit).
 constexpr uint32_t kMaxResidentSpheres = 512;
+// Triangles per LDS tile of the streaming kernels (three float4 each: 12 KiB), and the most a resident scene holds.
+constexpr uint32_t kTileTriangles = 256;
+constexpr uint32_t kMaxResidentTriangles = 256;
 // ... and only while spheres, materials and lights together stay below this many bytes of LDS
 // (a scene may carry far more materials than spheres).
 constexpr size_t kMaxResidentBytes = 24 * 1024;
@@ -87,6 +90,10 @@ struct SceneParams {
     const float4 *light; // (r, g, b, -) intensity
     const float4 *light_geom; // point light: (x, y, z, bits 0); area light: (bits sphere index, -, -, bits 1)
     uint32_t n_prims, n_mats, n_lights;
+    // Triangles (path pool only): four float4 per triangle -- (v0, material id bits), (v1 - v0, light id bits),
+    // (v2 - v0, -), (unit normal, -); triangle k is primitive n_prims + k
+    const float4 *tri;
+    uint32_t n_tris;
 };
 
 // Megakernel argument, passed by value (wave-uniform, lives in SGPRs).

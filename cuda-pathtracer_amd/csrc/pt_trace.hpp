@@ -28,7 +28,7 @@ PT_DEV float wave_read(float x, int src)
 // Bytes of LDS stage_scene<false>() fills, rounded up to 16 (device-side twin of scene_lds_bytes).
 PT_DEV uint32_t scene_lds_bytes_dev(const SceneParams &s)
 {
-    const uint32_t n = s.n_prims * 32u + s.n_mats * 24u + s.n_lights * 16u;
+    const uint32_t n = s.n_prims * 32u + s.n_mats * 24u + s.n_lights * 16u + s.n_tris * 64u;
     return (n + 15u) & ~15u;
 }
 
@@ -38,6 +38,7 @@ struct SceneView {
     const float4 *mat;   // (r, g, b, coef)
     const int2 *mat_type;   // (MaterialType, bits of 1.f / coef)
     const float4 *light; // (r, g, b, -)
+    const float4 *tri;   // resident scenes with triangles: four float4 per triangle in LDS (else device memory)
 };
 
 // Resident scenes: copy spheres, aux, materials and lights into LDS (one barrier inside).
@@ -61,10 +62,15 @@ PT_DEV SceneView stage_scene(const SceneParams &p, unsigned char *lds_raw, int t
             lds_type[i] = p.mat_type[i];
         }
         for (uint32_t i = tid; i < p.n_lights; i += kBlockThreads) lds_light[i] = p.light[i];
+        // triangles behind the 8-byte type entries, on the next 16-byte boundary
+        float4 *lds_tri = reinterpret_cast<float4 *>(lds_raw + ((p.n_prims * 32u + p.n_mats * 24u + p.n_lights * 16u + 15u) & ~15u));
+        for (uint32_t i = tid; i < p.n_tris * 4u; i += kBlockThreads) lds_tri[i] = p.tri[i];
         __syncthreads();
         sc.sph = lds_sph; sc.aux = lds_aux; sc.mat = lds_mat; sc.mat_type = lds_type; sc.light = lds_light;
+        sc.tri = lds_tri;
     } else {
         sc.sph = lds_sph; sc.aux = p.aux; sc.mat = p.mat; sc.mat_type = p.mat_type; sc.light = p.light;
+        sc.tri = p.tri;
     }
     return sc;
 }
@@ -519,9 +525,43 @@ PT_DEV void intersect_bvh(const BvhParams &B, const float4 *sph, uint32_t n_prim
 #endif
 }
 
+// One triangle of the scan, in the part of Primitive::Intersect (primitive.h:39-45).  No counterpart in
+// the reference, whose only primitive is the sphere (primitive.h:25-28).  Moeller-Trumbore in fp32, every
+// operation in the order the CPU oracle performs it (no fused multiply-add, correctly rounded 1/det), both
+// sides of the triangle.  t0 = (v0, -), t1 = (v1 - v0, -), t2 = (v2 - v0, -).  A degenerate triangle or a ray
+// in its plane has det == 0: 1/det is infinite, u infinite or NaN, and the first test fails like every NaN.
+PT_DEV void triangle_test(float4 t0, float4 t1, float4 t2, int index, V3 o, V3 d, float &tmax, int &best)
+{
+    const V3 e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
+    const V3 p = cross(d, e2);
+    const float det = dot(e1, p);
+    const float inv = pt_rcp(det);
+    const V3 s = o - mk(t0.x, t0.y, t0.z);
+    const float u = dot(s, p) * inv;
+    if (u >= 0.f && u <= 1.f) {
+        const V3 q = cross(s, e1);
+        const float v = dot(d, q) * inv;
+        if (v >= 0.f && u + v <= 1.f) {
+            const float t = dot(e2, q) * inv;
+            if (t > PT_EPSILON && t < tmax) { tmax = t; best = index; }
+        }
+    }
+}
+
+// The triangles of a scene behind its spheres (indices first_index ...), `tri` holding `stride` float4 per
+// triangle of which the first three are read.
+PT_DEV void scan_triangles(const float4 *tri, int stride, int first_index, int count, V3 o, V3 d, float &tmax, int &best)
+{
+    for (int k = 0; k < count; ++k) {
+        const float4 *t = tri + (size_t)k * stride;
+        triangle_test(t[0], t[1], t[2], first_index + k, o, d, tmax, best);
+    }
+}
+
 // Intersect (scene.h:71-94).  With TILED every thread of the workgroup must call it (barriers in
 // the scan, wave-wide cooperation in the BVH search); `active` masks the lanes that carry a ray.
-template <bool TILED, bool BVH = false>
+// TRI: the scene's triangles continue the scan behind the spheres (linear scan only).
+template <bool TILED, bool BVH = false, bool TRI = false>
 PT_DEV void intersect_scene(const SceneParams &p, const SceneView &sc, unsigned char *lds_raw, int tid,
                             bool active, V3 o, V3 d, float &tmax, int &best, float tmax0 = PT_INF)
 {
@@ -538,8 +578,23 @@ PT_DEV void intersect_scene(const SceneParams &p, const SceneView &sc, unsigned 
             __syncthreads();
             if (active) scan_lds_sparse(lds_sph, (int)base, (int)count, o, d, tmax, best);
         }
+        if (TRI) {   // the triangles pass through the same LDS tile, three float4 each
+            for (uint32_t base = 0; base < p.n_tris; base += kTileTriangles) {
+                const uint32_t count = min(kTileTriangles, p.n_tris - base);
+                __syncthreads();
+                for (uint32_t i = tid; i < count * 3u; i += kBlockThreads) {
+                    const uint32_t k = i / 3u;
+                    lds_sph[i] = p.tri[(size_t)(base + k) * 4u + (i - k * 3u)];
+                }
+                __syncthreads();
+                if (active) scan_triangles(lds_sph, 3, (int)(p.n_prims + base), (int)count, o, d, tmax, best);
+            }
+        }
     } else {
         if (active) scan_lds(sc.sph, 0, (int)p.n_prims, o, d, tmax, best);
+        if (TRI) {
+            if (active) scan_triangles(sc.tri, 4, (int)p.n_prims, (int)p.n_tris, o, d, tmax, best);
+        }
     }
 }
 
@@ -594,16 +649,13 @@ PT_DEV void camera_rays4(const CameraParams &cam, uint32_t x, uint32_t y, uint32
 // returns true when the path ends -- o, d and T are then left in whatever state the exit found
 // them in (a path that has ended has no use for them), which spares the copies that keeping
 // their old values across the exits would cost.
-PT_DEV bool shade_bounce(const SceneView &sc, float4 s, int best, float t, uint32_t pix, uint32_t it,
-                         uint32_t k0, uint32_t k1, int mb, V3 &o, V3 &d, V3 &T, V3 &L, int &b)
+//
+// shade_surface is the part behind the hit point and the normal: o is the hit point already, n the normal
+// of the primitive there, mat_id / light_id its material and light.
+PT_DEV bool shade_surface(const SceneView &sc, V3 n, uint32_t mat_id, int light_id, uint32_t pix, uint32_t it,
+                          uint32_t k0, uint32_t k1, int mb, V3 &o, V3 &d, V3 &T, V3 &L, int &b)
 {
-    // hit point and normal: scene.h:86-87, primitive.h:74
-    const float4 a = sc.aux[best];
     const V3 wo = d;
-    o = o + d * t;
-    const V3 n = (o - mk(s.x, s.y, s.z)) * a.x;
-    const uint32_t mat_id = __float_as_uint(a.y);
-    const int light_id = __float_as_int(a.z);
 
     // emission on every light hit: pathtracer.cu:134-137, Light::L light.h:43-45
     PT_LS(5);
@@ -636,6 +688,26 @@ PT_DEV bool shade_bounce(const SceneView &sc, float4 s, int best, float t, uint3
     if (b == mb) end = true;
     ++b;
     return end;
+}
+
+PT_DEV bool shade_bounce(const SceneView &sc, float4 s, int best, float t, uint32_t pix, uint32_t it,
+                         uint32_t k0, uint32_t k1, int mb, V3 &o, V3 &d, V3 &T, V3 &L, int &b)
+{
+    // hit point and normal: scene.h:86-87, primitive.h:74
+    const float4 a = sc.aux[best];
+    o = o + d * t;
+    const V3 n = (o - mk(s.x, s.y, s.z)) * a.x;
+    return shade_surface(sc, n, __float_as_uint(a.y), __float_as_int(a.z), pix, it, k0, k1, mb, o, d, T, L, b);
+}
+
+// The same for a hit on triangle k of the scene (primitive n_prims + k): the hit point o + d * t, the
+// triangle's own unit normal (computed by the host when the scene is uploaded), its material and light.
+PT_DEV bool shade_bounce_triangle(const SceneView &sc, const float4 *tri4, float t, uint32_t pix, uint32_t it,
+                                  uint32_t k0, uint32_t k1, int mb, V3 &o, V3 &d, V3 &T, V3 &L, int &b)
+{
+    const float4 t0 = tri4[0], t1 = tri4[1], t3 = tri4[3];
+    o = o + d * t;
+    return shade_surface(sc, mk(t3.x, t3.y, t3.z), __float_as_uint(t0.w), __float_as_int(t1.w), pix, it, k0, k1, mb, o, d, T, L, b);
 }
 
 // RenderKernel's accumulation (pathtracer.cu:101-109): c is the in-order sum of the pixel's four

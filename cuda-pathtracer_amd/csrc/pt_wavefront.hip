@@ -440,9 +440,12 @@ struct PoolEntry { float dx, dy, dz; uint32_t pix, it_sub; };
 // from its camera ray to its end and stores its radiance once.
 // NEE_MODE: 0 the path integrator, 1 the direct-light integrator with a shadow pass, 2 with a second scan
 // (see the loop body).
-template <bool TILED, int NEE_MODE>
+// TRI: the scene has triangles behind its spheres (path integrator only): they continue the scan, and a hit on
+// one is shaded with the triangle's own normal.
+template <bool TILED, int NEE_MODE, bool TRI = false>
 __global__ __launch_bounds__(kBlockThreads, NEE_MODE == 2 ? PT_NEE_POOL_WAVES : NEE_MODE == 1 ? PT_NEE_SHADOW_PASS_WAVES : 1) void wf_pool_kernel(const WavefrontParams p)
 {
+    static_assert(!(TRI && NEE_MODE != 0), "the direct-light integrator samples spheres only");
     constexpr bool NEE = NEE_MODE != 0;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int tid = threadIdx.x;
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(kBlockThreads, NEE_MODE == 2 ? PT_NEE_POOL_WAVES : 
             constexpr bool kShadowPass = NEE_MODE == 1;
             const bool shadow = kShadowPass && has && st.shadow;   // this pass answers the shadow query of the vertex shaded last
             if (kShadowPass) intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, has, o, shadow ? st.sh_d : d, tmax, best, shadow ? st.sh_tmax : PT_INF);
-            else             intersect_scene<TILED, false>(p.scene, sc, lds_raw, tid, has, o, d, tmax, best);
+            else             intersect_scene<TILED, false, TRI>(p.scene, sc, lds_raw, tid, has, o, d, tmax, best);
             bool cont = false, end = true;
             // without a shadow pass the shadow ray's fields live inside one pass only: a pass-local copy,
             // so that they hold no registers across the loop
@@ -580,7 +583,12 @@ __global__ __launch_bounds__(kBlockThreads, NEE_MODE == 2 ? PT_NEE_POOL_WAVES : 
                     }
                 } else {
                     record_hit(p, n_pix, pix, it_sub, b, best);
-                    if (best >= 0) end = shade_bounce(sc, (TILED ? p.scene.sph : sc.sph)[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
+                    if (TRI && best >= (int)p.scene.n_prims) {
+                        const float4 *tri4 = (TILED ? p.scene.tri : sc.tri) + 4 * (size_t)(best - (int)p.scene.n_prims);
+                        end = shade_bounce_triangle(sc, tri4, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
+                    } else if (best >= 0) {
+                        end = shade_bounce(sc, (TILED ? p.scene.sph : sc.sph)[best], best, tmax, pix, it_sub >> 2, k0, k1, p.max_bounces, o, d, T, L, b);
+                    }
                 }
             }
             if (NEE && !kShadowPass) {
@@ -720,6 +728,9 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
             if (tiled) hipLaunchKernelGGL((wf_pool_kernel<true, 1>), pool_grid, block, pool_lds, stream, p);
             else if (p.scene.n_prims > kMaxRingSpheres) hipLaunchKernelGGL((wf_pool_kernel<false, 1>), pool_grid, block, pool_lds, stream, p);
             else       hipLaunchKernelGGL((wf_pool_kernel<false, 2>), pool_grid, block, pool_lds, stream, p);
+        } else if (p.scene.n_tris) {
+            if (tiled) hipLaunchKernelGGL((wf_pool_kernel<true, 0, true>), pool_grid, block, pool_lds, stream, p);
+            else       hipLaunchKernelGGL((wf_pool_kernel<false, 0, true>), pool_grid, block, pool_lds, stream, p);
         } else if (tiled) hipLaunchKernelGGL((wf_pool_kernel<true, 0>), pool_grid, block, pool_lds, stream, p);
         else              hipLaunchKernelGGL((wf_pool_kernel<false, 0>), pool_grid, block, pool_lds, stream, p);
         return hipGetLastError();

@@ -63,6 +63,19 @@ typedef struct {
     int32_t light_id; /* -1: not a light (primitive.h:31,75) */
 } pt_sphere;
 
+/* A triangle primitive: NO counterpart in the reference, whose only primitive is the sphere
+ * ("will be changed to triangle later", primitive.h:25-28); results on scenes with triangles are
+ * therefore not pinned to the reference, only to this build's own CPU oracle.  Triangle k has the
+ * primitive index n_spheres + k (hit ids, pt_light.u.prim_id).  Intersection: Moeller-Trumbore in
+ * fp32, both sides, t within (EPSILON, tmax) like Primitive::Intersect (primitive.h:39-45); the
+ * geometric normal normalize((v1 - v0) x (v2 - v0)) stands in for Primitive::Normal and is never
+ * flipped (emission is one-sided with respect to it, light.h:43-45). */
+typedef struct {
+    float v0[3], v1[3], v2[3];
+    uint32_t material_id;
+    int32_t light_id; /* -1: not a light */
+} pt_triangle;
+
 /* light.h:34 */
 enum { PT_POINT_LIGHT = 0, PT_AREA_LIGHT = 1 };
 /* light.h:47-52 */
@@ -98,6 +111,17 @@ int pt_create(pt_handle *out, const pt_camera_pod *camera, int max_bounces, uint
 int pt_init_scene(pt_handle h, const pt_material *materials, uint32_t n_materials,
                   const pt_sphere *spheres, uint32_t n_spheres,
                   const pt_light *lights, uint32_t n_lights);
+
+/* pt_init_scene with triangles beside the spheres (either array may be empty).  An extension without a
+ * counterpart in the reference (see pt_triangle).  Scenes with triangles are rendered by the linear scan
+ * (spheres, then triangles, in index order: the lowest index wins equal distances, scene.h:78-80) through
+ * the path pool -- PT_VARIANT_AUTO, PT_INTEGRATOR_PATH, pt_run / pt_run_n / pt_run_async; no BVH is built
+ * for them, and the other kernel variants, pt_run_n_noalloc and the NEE integrator (whose light sampling,
+ * primitive.h:50-72, is written for spheres) answer PT_ERR_STATE. */
+int pt_init_scene_triangles(pt_handle h, const pt_material *materials, uint32_t n_materials,
+                            const pt_sphere *spheres, uint32_t n_spheres,
+                            const pt_triangle *triangles, uint32_t n_triangles,
+                            const pt_light *lights, uint32_t n_lights);
 
 /* Pathtracer::Release, pathtracer.cu:249-258, plus destruction of the handle. */
 int pt_destroy(pt_handle h);

@@ -22,6 +22,8 @@ MATERIAL_DTYPE = np.dtype([("color", "<f4", 3), ("coef", "<f4"), ("type", "<i4")
 SPHERE_DTYPE = np.dtype([("pos", "<f4", 3), ("radius", "<f4"), ("material_id", "<u4"),
                          ("light_id", "<i4")])
 LIGHT_DTYPE = np.dtype([("type", "<i4"), ("u_bits", "<u4", 3), ("intensity", "<f4", 3)])
+TRIANGLE_DTYPE = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3), ("material_id", "<u4"),
+                           ("light_id", "<i4")])
 
 ACCUM_RUNNING_MEAN, ACCUM_SUM = 0, 1
 HIT_MISS, HIT_NOT_TRACED = -1, -2
@@ -104,9 +106,13 @@ INTEGRATOR_PATH, INTEGRATOR_NEE_MIS = 0, 1
 
 def oracle_render(cam_pod, mats, prims, lights, seed, max_bounces, first_iteration=1, n_iterations=1,
                   rect=None, accum_mode=ACCUM_RUNNING_MEAN, buffer=None, want_paths=False, n_threads=1,
-                  integrator=INTEGRATOR_PATH):
-    """Returns (buffer[h,w,3], hit_ids or None, path_radiance or None, ray_count)."""
+                  integrator=INTEGRATOR_PATH, triangles=None):
+    """Returns (buffer[h,w,3], hit_ids or None, path_radiance or None, ray_count).
+    triangles (TRIANGLE_DTYPE, optional): this build's extension, primitives behind the spheres."""
     lib = load_oracle()
+    if triangles is not None and len(triangles):
+        return _oracle_render_tri(lib, cam_pod, mats, prims, triangles, lights, seed, max_bounces, first_iteration,
+                                  n_iterations, rect, accum_mode, buffer, want_paths, n_threads, integrator)
     lib.ptor_render_with.restype = _i32
     lib.ptor_render_with.argtypes = [_i32] + list(lib.ptor_render.argtypes)
     cam_pod = np.ascontiguousarray(cam_pod, CAMERA_DTYPE)
@@ -124,6 +130,37 @@ def oracle_render(cam_pod, mats, prims, lights, seed, max_bounces, first_iterati
     if rc != 0:
         raise ValueError("ptor_render: invalid arguments")
     return buffer, hits, rad, int(cnt.value)
+
+
+def _oracle_render_tri(lib, cam_pod, mats, prims, triangles, lights, seed, max_bounces, first_iteration, n_iterations,
+                       rect, accum_mode, buffer, want_paths, n_threads, integrator):
+    lib.ptor_render_tri.restype = _i32
+    cam_pod = np.ascontiguousarray(cam_pod, CAMERA_DTYPE)
+    width, height = int(cam_pod["width"].reshape(-1)[0]), int(cam_pod["height"].reshape(-1)[0])
+    rect = rect or (0, 0, width, height)
+    mats = np.ascontiguousarray(mats, MATERIAL_DTYPE)
+    prims = np.ascontiguousarray(prims, SPHERE_DTYPE)
+    tris = np.ascontiguousarray(triangles, TRIANGLE_DTYPE)
+    lights = np.ascontiguousarray(lights, LIGHT_DTYPE)
+    buffer, hits, rad = _outputs(width, height, rect, n_iterations, max_bounces, buffer, want_paths)
+    cnt = _u64(0)
+    u32 = ctypes.c_uint32
+    args = [_i32(integrator), _ptr(cam_pod), _ptr(mats), u32(len(mats)), _ptr(prims), u32(len(prims)), _ptr(tris), u32(len(tris)),
+            _ptr(lights), u32(len(lights)), _u64(seed), _i32(max_bounces), u32(first_iteration), u32(n_iterations),
+            *[u32(v) for v in rect], _i32(accum_mode), _ptr(buffer), _ptr(hits), _ptr(rad), ctypes.byref(cnt), _i32(n_threads)]
+    if lib.ptor_render_tri(*args) != 0:
+        raise ValueError("ptor_render_tri: invalid arguments")
+    return buffer, hits, rad, int(cnt.value)
+
+
+def triangle_intersect(tri, o, d, tmin=0.03, tmax=3.402823466e+38):
+    """Oracle: one ray against one triangle (TRIANGLE_DTYPE record); t or -1."""
+    lib = load_oracle()
+    lib.ptor_triangle_intersect.restype = ctypes.c_float
+    t = np.ascontiguousarray(tri, TRIANGLE_DTYPE).reshape(1)
+    o = np.ascontiguousarray(o, np.float32)
+    d = np.ascontiguousarray(d, np.float32)
+    return float(lib.ptor_triangle_intersect(_ptr(t), _ptr(o), _ptr(d), ctypes.c_float(tmin), ctypes.c_float(tmax)))
 
 
 def ref_render(eye, look_at, up, width, height, fov, mats, prims, lights, seed, max_bounces,

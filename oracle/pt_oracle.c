@@ -52,12 +52,16 @@ typedef struct {
     uint64_t seed;
     int max_bounces;
     int integrator;
+    const ptor_triangle *tris; /* this build's extension, see pt_oracle.h; indices n_prims .. n_prims + n_tris - 1 */
+    uint32_t n_tris;
 } scene_ctx;
 
 typedef struct {
     int prim; /* index, -1 when nothing was hit */
     v3 p, n;
     float t;
+    uint32_t material_id; /* of the primitive hit (prim->materialId, pathtracer.cu:127) */
+    int32_t light_id;
 } isect_t;
 
 /* Primitive::Intersect, primitive.h:39-45 */
@@ -71,6 +75,33 @@ static inline float sphere_intersect(const ptor_sphere *s, v3 o, v3 d, float tmi
                                 : ((t = b + det) > tmin ? (t < tmax ? t : -1.f) : -1.f);
 }
 
+/* A triangle in the part of Primitive::Intersect (primitive.h:39-45: t within (tmin, tmax), else -1).
+ * No counterpart in the reference (parity unpinned).  Moeller-Trumbore (J. Graphics Tools 2(1), 1997)
+ * in fp32, every operation in the order written, no fused multiply-add, both sides of the triangle.
+ * A degenerate triangle or a ray in its plane gives det == 0, 1/det infinite and u infinite or NaN:
+ * rejected by the first test like every NaN. */
+static inline float triangle_intersect(const ptor_triangle *tr, v3 o, v3 d, float tmin, float tmax)
+{
+    const v3 v0 = v3_load(tr->v0);
+    const v3 e1 = v3_sub(v3_load(tr->v1), v0), e2 = v3_sub(v3_load(tr->v2), v0);
+    const v3 p = v3_cross(d, e2);
+    const float det = v3_dot(e1, p);
+    const float inv = 1.f / det;
+    const v3 s = v3_sub(o, v0);
+    const float u = v3_dot(s, p) * inv;
+    if (!(u >= 0.f && u <= 1.f)) return -1.f;
+    const v3 q = v3_cross(s, e1);
+    const float v = v3_dot(d, q) * inv;
+    if (!(v >= 0.f && u + v <= 1.f)) return -1.f;
+    const float t = v3_dot(e2, q) * inv;
+    return (t > tmin && t < tmax) ? t : -1.f;
+}
+
+float ptor_triangle_intersect(const ptor_triangle *tri, const float o[3], const float d[3], float tmin, float tmax)
+{
+    return triangle_intersect(tri, v3_load(o), v3_load(d), tmin, tmax);
+}
+
 /* Intersect, scene.h:71-94 (always called with &isect and the default tmin/tmax). */
 static int scene_intersect(const scene_ctx *sc, v3 o, v3 d, isect_t *isect)
 {
@@ -78,6 +109,7 @@ static int scene_intersect(const scene_ctx *sc, v3 o, v3 d, isect_t *isect)
     isect_t is;
     int found = 0;
     is.prim = -1; is.p = v3_make(0, 0, 0); is.n = v3_make(0, 0, 0); is.t = 0.f;
+    is.material_id = 0; is.light_id = -1;
     for (uint32_t i = 0; i < sc->n_prims; ++i) {
         float thit;
         const ptor_sphere *prim = &sc->prims[i];
@@ -88,6 +120,22 @@ static int scene_intersect(const scene_ctx *sc, v3 o, v3 d, isect_t *isect)
             is.p = v3_add(o, v3_scale(d, thit));                    /* geometry.h:343 */
             is.n = v3_div(v3_sub(is.p, v3_load(prim->pos)), prim->radius); /* primitive.h:74 */
             is.t = thit;
+            is.material_id = prim->material_id; is.light_id = prim->light_id;
+        }
+    }
+    /* the triangles continue the scan with the indices behind the spheres': same strict rule */
+    for (uint32_t k = 0; k < sc->n_tris; ++k) {
+        float thit;
+        const ptor_triangle *tr = &sc->tris[k];
+        if ((thit = triangle_intersect(tr, o, d, tmin, tmax)) > 0.f) {
+            const v3 v0 = v3_load(tr->v0);
+            tmax = thit;
+            found = 1;
+            is.prim = (int)(sc->n_prims + k);
+            is.p = v3_add(o, v3_scale(d, thit));
+            is.n = v3_normalize(v3_cross(v3_sub(v3_load(tr->v1), v0), v3_sub(v3_load(tr->v2), v0)));
+            is.t = thit;
+            is.material_id = tr->material_id; is.light_id = tr->light_id;
         }
     }
     *isect = is;
@@ -217,15 +265,14 @@ static v3 trace(const scene_ctx *sc, v3 o, v3 d, uint32_t pixel, uint32_t iterat
 
     isect_t isectp = isect;
     for (int bounces = 0;; ++bounces) {
-        const ptor_sphere *prim = &sc->prims[isectp.prim];
-        const ptor_material *mat = &sc->mats[prim->material_id];
+        const ptor_material *mat = &sc->mats[isectp.material_id];
         const v3 p = isectp.p;
         const v3 n = isectp.n;
         const v3 wo = d;
 
-        if (prim->light_id > -1) {
+        if (isectp.light_id > -1) {
             /* Light::L, light.h:43-45 */
-            const ptor_light *light = &sc->lights[prim->light_id];
+            const ptor_light *light = &sc->lights[isectp.light_id];
             v3 le = v3_dot(n, v3_neg(wo)) > 0.f ? v3_load(light->intensity) : v3_make(0.f, 0.f, 0.f);
             L = v3_add(L, v3_mul(T, le));
         }
@@ -495,9 +542,29 @@ int ptor_render_with(int integrator, const ptor_camera *cam,
                      int32_t *hit_ids, float *path_radiance, uint64_t *ray_count,
                      int n_threads)
 {
+    return ptor_render_tri(integrator, cam, mats, n_mats, prims, n_prims, NULL, 0, lights, n_lights, seed, max_bounces,
+                           first_iteration, n_iterations, x0, y0, x1, y1, accum_mode, buffer, hit_ids, path_radiance,
+                           ray_count, n_threads);
+}
+
+int ptor_render_tri(int integrator, const ptor_camera *cam,
+                    const ptor_material *mats, uint32_t n_mats,
+                    const ptor_sphere *prims, uint32_t n_prims,
+                    const ptor_triangle *tris, uint32_t n_tris,
+                    const ptor_light *lights, uint32_t n_lights,
+                    uint64_t seed, int max_bounces,
+                    uint32_t first_iteration, uint32_t n_iterations,
+                    uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                    int accum_mode, float *buffer,
+                    int32_t *hit_ids, float *path_radiance, uint64_t *ray_count,
+                    int n_threads)
+{
     if (integrator != PTOR_INTEGRATOR_PATH && integrator != PTOR_INTEGRATOR_NEE_MIS) return -1;
+    if (n_tris && (!tris || integrator != PTOR_INTEGRATOR_PATH)) return -1;
+    for (uint32_t i = 0; i < n_tris; ++i)
+        if (tris[i].material_id >= n_mats || tris[i].light_id >= (int32_t)n_lights) return -1;
     for (uint32_t i = 0; i < n_lights; ++i)
-        if (lights && lights[i].type == 1 && lights[i].u.prim_id >= n_prims) return -1;
+        if (lights && lights[i].type == 1 && lights[i].u.prim_id >= n_prims + n_tris) return -1;
     if (!cam || !buffer || max_bounces < 0 || first_iteration == 0) return -1;
     if (x1 > cam->width || y1 > cam->height || x0 > x1 || y0 > y1) return -1;
     if ((n_prims && !prims) || (n_mats && !mats) || (n_lights && !lights)) return -1;
@@ -505,7 +572,7 @@ int ptor_render_with(int integrator, const ptor_camera *cam,
         if (prims[i].material_id >= n_mats) return -1;
         if (prims[i].light_id >= (int32_t)n_lights) return -1;
     }
-    scene_ctx sc = { cam, mats, prims, lights, n_mats, n_prims, n_lights, seed, max_bounces, integrator };
+    scene_ctx sc = { cam, mats, prims, lights, n_mats, n_prims, n_lights, seed, max_bounces, integrator, tris, n_tris };
 
     uint32_t rows = y1 - y0;
     if (n_threads < 1) n_threads = 1;

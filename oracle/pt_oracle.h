@@ -43,6 +43,18 @@ typedef struct {
     int32_t light_id; /* -1: not a light */
 } ptor_sphere;
 
+/* A triangle primitive.  The reference has none -- primitive.h:25-28 says "Represents a sphere - will
+ * be changed to triangle later" -- so nothing here can be pinned to it (PARITY UNPINNED): this is the
+ * oracle of this build's own extension, stated in the reference's style.  Primitive k of the triangle
+ * array has index n_prims + k in hit_ids and in Light::prim_id; the geometric normal
+ * normalize((v1 - v0) x (v2 - v0)) plays the part of Primitive::Normal and is never flipped, like a
+ * sphere's outward normal (pathtracer.cu:130, light.h:43-45). */
+typedef struct {
+    float v0[3], v1[3], v2[3];
+    uint32_t material_id;
+    int32_t light_id; /* -1: not a light */
+} ptor_triangle;
+
 /* light.h:47-52 */
 typedef struct {
     int32_t type; /* 0 POINT_LIGHT, 1 AREA_LIGHT (light.h:34) */
@@ -152,6 +164,24 @@ int ptor_sample_material_eval(const ptor_material *mat, const float *in, float *
 int ptor_nee_eval(int op, int as_written,
                   const ptor_material *mats, uint32_t n_mats, const ptor_sphere *prims, uint32_t n_prims,
                   const ptor_light *lights, uint32_t n_lights, const float *in, float *out, uint32_t count);
+
+/* ptor_render_with over spheres AND triangles (tris may be NULL when n_tris == 0).  Path integrator
+ * only when there are triangles: the reference's light sampling (Primitive::Sample, primitive.h:50-72)
+ * is written for spheres.  Returns -1 otherwise. */
+int ptor_render_tri(int integrator, const ptor_camera *cam,
+                    const ptor_material *mats, uint32_t n_mats,
+                    const ptor_sphere *prims, uint32_t n_prims,
+                    const ptor_triangle *tris, uint32_t n_tris,
+                    const ptor_light *lights, uint32_t n_lights,
+                    uint64_t seed, int max_bounces,
+                    uint32_t first_iteration, uint32_t n_iterations,
+                    uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                    int accum_mode, float *buffer,
+                    int32_t *hit_ids, float *path_radiance, uint64_t *ray_count,
+                    int n_threads);
+
+/* Test hook: one ray against one triangle with the bounds (tmin, tmax): t, or -1. */
+float ptor_triangle_intersect(const ptor_triangle *tri, const float o[3], const float d[3], float tmin, float tmax);
 
 #ifdef __cplusplus
 }

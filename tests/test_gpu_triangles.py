@@ -1,0 +1,113 @@
+"""The triangle primitive on the GPU (path pool kernels, TRI leg) against the CPU oracle, bit for
+bit: hit-index sequences, per-path radiance, images, Intersect-call counts.  The primitive is this
+build's extension -- the reference has spheres only (primitive.h:25-28) -- so parity with the
+reference is UNPINNED for these scenes; what is pinned is GPU == oracle, and (test_triangles.py) the
+oracle against closed-form answers."""
+import numpy as np
+import pytest
+
+from triangle_scenes import box_room, triangle_soup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def compare(pt, O, torch, scene, w, h, depth, n, seed=1, trace=True):
+    mats, sph, tris, lights, (eye, look, up, fov) = scene
+    cam = pt.Camera(eye, look, up, w, h, 0, 0, fov)
+    tr = pt.Pathtracer(cam, depth, seed)
+    tr.Init(mats, sph, lights, triangles=tris)
+    assert tr.AccelNodes() == 0                      # no BVH for scenes with triangles
+    buf = torch.full((w * h * 3,), 3.0, dtype=torch.float32, device="cuda")
+    tr.ResetCounters()
+    tr.RunN(buf, n)
+    assert tr.LastLaunch() == pt.LAUNCH_PATH_POOL
+    ref, ref_hits, ref_rad, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, seed, depth, n_iterations=n, want_paths=trace,
+                                                       n_threads=8, triangles=tris)
+    assert tr.RayCount() == ref_rays
+    assert buf.cpu().numpy().tobytes() == np.ascontiguousarray(ref, np.float32).tobytes()
+    if trace:
+        hits, rad, _, rays = tr.DebugTrace(0, 0, w, h, 1)
+        assert np.array_equal(hits, ref_hits[0])
+        assert rad.tobytes() == np.ascontiguousarray(ref_rad[0], np.float32).tobytes()
+    # the same render as a series of asynchronous calls, and in row bands summed up
+    got = torch.zeros_like(buf)
+    tr.Reset()
+    for _ in range(n):
+        tr.RunAsync(got)
+    tr.Wait()
+    assert torch.equal(got, buf)
+    if h >= 32:
+        total = torch.zeros_like(buf)
+        for rank in range(2):
+            part = torch.zeros_like(buf)
+            tr.SetRowBands(16, rank, 2)
+            tr.Reset()
+            tr.RunN(part, n)
+            total += part
+        tr.SetRowBands(16, 0, 1)
+        assert torch.equal(total, buf)
+    tr.Release()
+    return ref
+
+
+def test_box_room_of_triangles(pt, O, torch_cuda):
+    img = compare(pt, O, torch_cuda, box_room(pt), 64, 48, 8, 4)
+    assert 0.05 < img.mean() < 5.0
+
+
+@pytest.mark.parametrize("seed,n_tris,n_spheres,depth", [(1, 40, 0, 8), (2, 200, 30, 16), (3, 12, 9, 4), (4, 256, 150, 8), (5, 1, 0, 2)])
+def test_resident_triangle_soups(pt, O, torch_cuda, seed, n_tris, n_spheres, depth):
+    rng = np.random.default_rng(seed)
+    compare(pt, O, torch_cuda, triangle_soup(pt, rng, n_tris, n_spheres), 57, 35, depth, 2, seed=seed)
+
+
+@pytest.mark.parametrize("seed,n_tris,n_spheres", [(11, 700, 600), (12, 257, 3), (13, 300, 1100)])
+def test_streamed_triangle_soups(pt, O, torch_cuda, seed, n_tris, n_spheres):
+    """More triangles or spheres than stay resident in LDS: both pass through the LDS tile, spheres first."""
+    rng = np.random.default_rng(seed)
+    compare(pt, O, torch_cuda, triangle_soup(pt, rng, n_tris, n_spheres), 48, 33, 8, 2, seed=seed)
+
+
+def test_what_triangles_do_not_support_is_refused(pt, torch_cuda):
+    mats, sph, tris, lights, (eye, look, up, fov) = box_room(pt)
+    cam = pt.Camera(eye, look, up, 32, 32, 0, 0, fov)
+    tr = pt.Pathtracer(cam, 4, 1)
+    tr.Init(mats, sph, lights, triangles=tris)
+    buf = torch_cuda.zeros(32 * 32 * 3, device="cuda")
+    tr.SetIntegrator(pt.INTEGRATOR_NEE_MIS)
+    with pytest.raises(pt.PtError) as e:
+        tr.RunN(buf, 1)
+    assert e.value.code == pt.PT_ERR_STATE and "NEE" in str(e.value)
+    tr.SetIntegrator(pt.INTEGRATOR_PATH)
+    for variant in (pt.VARIANT_REGENERATION, pt.VARIANT_STEALING, pt.VARIANT_WAVEFRONT, pt.VARIANT_CLASSIC):
+        tr.SetKernelVariant(variant)
+        with pytest.raises(pt.PtError) as e:
+            tr.RunN(buf, 1)
+        assert e.value.code == pt.PT_ERR_STATE
+    tr.SetKernelVariant(pt.VARIANT_AUTO)
+    with pytest.raises(pt.PtError) as e:
+        tr.RunNNoAlloc(buf, 1)
+    assert e.value.code == pt.PT_ERR_STATE
+    assert tr.GetIteration() == 0
+    tr.RunN(buf, 1)                                   # and the supported path still works afterwards
+    assert tr.GetIteration() == 1
+    # bad references are caught when the scene is uploaded
+    bad = tris.copy(); bad["light_id"][0] = 5
+    with pytest.raises(pt.PtError) as e:
+        tr.Init(mats, sph, lights, triangles=bad)
+    assert e.value.code == pt.PT_ERR_INVALID
+    # a scene without triangles after one with: everything is allowed again
+    g_mats, g_sph, g_lights, _ = pt.build_scene(pt.SCENE_DEMO, 1)
+    tr.Init(g_mats, g_sph, g_lights)
+    tr.SetKernelVariant(pt.VARIANT_STEALING)
+    tr.Reset()
+    tr.RunN(buf, 1)
+    tr.Release()

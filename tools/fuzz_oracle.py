@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised comparison of the shipped kernels with the CPU oracle (the restatement of the
 reference's trace loop): random small frames, depths, iteration counts and scenes (built-in ones
-and random sphere clouds of all three materials, through the linear scan or the BVH); frame
+and random sphere clouds of all three materials, through the linear scan or the BVH), both integrators,
+one call or a series of asynchronous calls; frame
 buffers and Intersect-call counts must agree bit for bit.
 
     python tools/fuzz_oracle.py [n_cases] [first_seed]      (on the GPU box)"""
@@ -36,19 +37,30 @@ def one_case(seed):
     n = int(rng.choice([1, 2, 3, 6]))
     variant = int(rng.choice([pt.VARIANT_AUTO, pt.VARIANT_AUTO, pt.VARIANT_STEALING, pt.VARIANT_WAVEFRONT]))
     accel = pt.ACCEL_BRUTE_FORCE if rng.random() < 0.3 else pt.ACCEL_AUTO
+    # the direct-light integrator (the wavefront variant's per-bounce queues do not carry it), and the
+    # render as a series of pt_run_async calls
+    nee = variant != pt.VARIANT_WAVEFRONT and rng.random() < 0.4
+    use_async = rng.random() < 0.3
     cam = pt.Camera(eye, look, up, w, h, 0, 0, fov)
-    ref, _, _, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, seed & 0xffff, depth, n_iterations=n, n_threads=16)
+    ref, _, _, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, seed & 0xffff, depth, n_iterations=n, n_threads=16,
+                                          integrator=O.INTEGRATOR_NEE_MIS if nee else O.INTEGRATOR_PATH)
     tr = pt.Pathtracer(cam, depth, seed & 0xffff)
     tr.Init(mats, sph, lights)
     tr.SetAccel(accel)
     tr.SetKernelVariant(variant)
+    tr.SetIntegrator(pt.INTEGRATOR_NEE_MIS if nee else pt.INTEGRATOR_PATH)
     tr.ResetCounters()
     buf = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
-    tr.RunN(buf, n)
+    if use_async:
+        for _ in range(n):
+            tr.RunAsync(buf)
+        tr.Wait()
+    else:
+        tr.RunN(buf, n)
     torch.cuda.synchronize()
     ok = buf.cpu().numpy().tobytes() == np.ascontiguousarray(ref, np.float32).tobytes() and tr.RayCount() == ref_rays
     tr.Release()
-    return ok, (kind, len(sph), w, h, depth, n, variant, accel)
+    return ok, (kind, len(sph), w, h, depth, n, variant, accel, nee, use_async)
 
 
 def main():
