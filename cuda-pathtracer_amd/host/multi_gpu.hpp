@@ -51,7 +51,7 @@ struct MultiGpuResult {
 inline MultiGpuResult RenderMultiGpu(const Camera &camera, int bounces, uint64_t seed, const std::vector<Material> &mv,
                                      const std::vector<Primitive> &pv, const std::vector<Light> &lv, int accel,
                                      uint32_t world, SplitMode split, uint32_t iterations, uint32_t batch,
-                                     int inject_failure_rank = -1)
+                                     int inject_failure_rank = -1, const std::vector<Triangle> &tv = std::vector<Triangle>())
 {
     MultiGpuResult res;
     int n_dev = 0;
@@ -95,7 +95,7 @@ inline MultiGpuResult RenderMultiGpu(const Camera &camera, int bounces, uint64_t
             else if (hipMemsetAsync(buffers[rank], 0, n * sizeof(float), streams[rank]) != hipSuccess) err = "hipMemsetAsync failed";
             else {
                 pt.reset(new Pathtracer(&cam, bounces, seed));
-                if (!pt->Init(mv, pv, lv)) err = pt->LastError();
+                if (!pt->Init(mv, pv, tv, lv)) err = pt->LastError();
             }
             if (err.empty()) {
                 pt->SetAccel(accel);

@@ -111,6 +111,19 @@ public:
     int lightId;
 };
 
+// Not in the reference (its only primitive is the sphere): a triangle, both sides hit, with its
+// geometric normal normalize((v1 - v0) x (v2 - v0)).  Triangle k of a scene is primitive
+// <number of spheres> + k for the lights' primId.
+class Triangle {
+public:
+    Triangle(const Point &a, const Point &b, const Point &c, uint32_t matId, int lightId_ = -1)
+        : v0(a), v1(b), v2(c), materialId(matId), lightId(lightId_) {}
+    bool IsLight() const { return lightId > -1; }
+    Point v0, v1, v2;
+    uint32_t materialId;
+    int lightId;
+};
+
 enum LightType { POINT_LIGHT = PT_POINT_LIGHT, AREA_LIGHT = PT_AREA_LIGHT };
 
 // light.h:36-53
@@ -139,6 +152,12 @@ public:
     // pathtracer.cu:172-220
     bool Init(const std::vector<Material> &mv, const std::vector<Primitive> &pv, const std::vector<Light> &lv)
     {
+        return Init(mv, pv, std::vector<Triangle>(), lv);
+    }
+    // The same with triangles beside the spheres (not in the reference).
+    bool Init(const std::vector<Material> &mv, const std::vector<Primitive> &pv, const std::vector<Triangle> &tv,
+              const std::vector<Light> &lv)
+    {
         std::vector<pt_material> m(mv.size());
         std::vector<pt_sphere> p(pv.size());
         std::vector<pt_light> l(lv.size());
@@ -157,8 +176,15 @@ public:
             else { l[i].u.pos[0] = lv[i].pos.x; l[i].u.pos[1] = lv[i].pos.y; l[i].u.pos[2] = lv[i].pos.z; }
             l[i].intensity[0] = lv[i].intensity.r; l[i].intensity[1] = lv[i].intensity.g; l[i].intensity[2] = lv[i].intensity.b;
         }
-        return pt_init_scene(handle_, m.data(), (uint32_t)m.size(), p.data(), (uint32_t)p.size(),
-                             l.data(), (uint32_t)l.size()) == PT_OK;
+        std::vector<pt_triangle> t(tv.size());
+        for (size_t i = 0; i < tv.size(); ++i) {
+            const Point *v[3] = {&tv[i].v0, &tv[i].v1, &tv[i].v2};
+            float *dst[3] = {t[i].v0, t[i].v1, t[i].v2};
+            for (int k = 0; k < 3; ++k) { dst[k][0] = v[k]->x; dst[k][1] = v[k]->y; dst[k][2] = v[k]->z; }
+            t[i].material_id = tv[i].materialId; t[i].light_id = tv[i].lightId;
+        }
+        return pt_init_scene_triangles(handle_, m.data(), (uint32_t)m.size(), p.data(), (uint32_t)p.size(),
+                                       t.data(), (uint32_t)t.size(), l.data(), (uint32_t)l.size()) == PT_OK;
     }
 
     // pathtracer.cu:222-243.  The reference re-reads *camera on every Run (pathtracer.cu:232).

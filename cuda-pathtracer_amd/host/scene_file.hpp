@@ -12,6 +12,9 @@
 //     sphere   x y z   radius   material_index
 //     light    sphere_index   r g b            # the sphere emits (area light, light.h:43-45)
 //     pointlight x y z   r g b                 # kept in the light list; Trace never reads it
+//     triangle x0 y0 z0  x1 y1 z1  x2 y2 z2  material_index     # not in the reference; hit from both sides
+//     trianglelight triangle_index   r g b     # the triangle emits on the side of (v1-v0) x (v2-v0)
+// Triangles are primitives <number of spheres> + k to the library, whatever the order of the statements.
 #pragma once
 
 #include "pathtracer.hpp"
@@ -32,7 +35,8 @@ struct SceneDescription {
     float fov = 60.f;
     std::vector<Material> materials;
     std::vector<Primitive> primitives;
-    std::vector<Light> lights;
+    std::vector<Triangle> triangles;
+    std::vector<Light> lights;   // area lights on triangles: primId = primitives.size() + triangle index
 };
 
 // Returns an empty string on success, otherwise "line N: what is wrong".
@@ -41,6 +45,7 @@ inline std::string ParseScene(std::istream &in, SceneDescription *out)
     *out = SceneDescription();
     std::string line;
     int lineno = 0;
+    std::vector<size_t> triangle_lights;   // lights whose primId still is a triangle index
     auto err = [&lineno](const std::string &what) { return "line " + std::to_string(lineno) + ": " + what; };
     while (std::getline(in, line)) {
         ++lineno;
@@ -89,6 +94,21 @@ inline std::string ParseScene(std::istream &in, SceneDescription *out)
             if (out->primitives[(size_t)prim].IsLight()) return err("sphere " + std::to_string(prim) + " already is a light");
             out->primitives[(size_t)prim].lightId = (int)out->lights.size();
             out->lights.push_back(Light((uint32_t)prim, Color(v[0], v[1], v[2])));
+        } else if (kw == "triangle") {
+            float v[9];
+            long mat = -1;
+            if (!floats(v, 9) || !(ss >> mat) || !at_end()) return err("triangle needs three corners (x y z each) and material_index");
+            if (mat < 0 || (size_t)mat >= out->materials.size()) return err("triangle refers to material " + std::to_string(mat) + ", which is not defined above");
+            out->triangles.push_back(Triangle(Point(v[0], v[1], v[2]), Point(v[3], v[4], v[5]), Point(v[6], v[7], v[8]), (uint32_t)mat));
+        } else if (kw == "trianglelight") {
+            long tri = -1;
+            float v[3];
+            if (!(ss >> tri) || !floats(v, 3) || !at_end()) return err("trianglelight needs triangle_index r g b");
+            if (tri < 0 || (size_t)tri >= out->triangles.size()) return err("trianglelight refers to triangle " + std::to_string(tri) + ", which is not defined above");
+            if (out->triangles[(size_t)tri].IsLight()) return err("triangle " + std::to_string(tri) + " already is a light");
+            out->triangles[(size_t)tri].lightId = (int)out->lights.size();
+            triangle_lights.push_back(out->lights.size());
+            out->lights.push_back(Light((uint32_t)tri, Color(v[0], v[1], v[2])));
         } else if (kw == "pointlight") {
             float v[6];
             if (!floats(v, 6) || !at_end()) return err("pointlight needs x y z r g b");
@@ -97,7 +117,8 @@ inline std::string ParseScene(std::istream &in, SceneDescription *out)
             return err("unknown statement '" + kw + "'");
         }
     }
-    if (out->primitives.empty()) { ++lineno; return err("the scene has no sphere"); }
+    if (out->primitives.empty() && out->triangles.empty()) { ++lineno; return err("the scene has no sphere and no triangle"); }
+    for (size_t l : triangle_lights) out->lights[l].primId += (uint32_t)out->primitives.size();
     return std::string();
 }
 
@@ -120,8 +141,13 @@ inline void WriteScene(FILE *f, const SceneDescription &s)
         fprintf(f, "material %s %.9g %.9g %.9g %.9g\n", names[(int)m.type], m.color.r, m.color.g, m.color.b, m.coef);
     for (const Primitive &p : s.primitives)
         fprintf(f, "sphere %.9g %.9g %.9g %.9g %u\n", p.pos.x, p.pos.y, p.pos.z, p.radius, p.materialId);
+    for (const Triangle &t : s.triangles)
+        fprintf(f, "triangle %.9g %.9g %.9g  %.9g %.9g %.9g  %.9g %.9g %.9g  %u\n", t.v0.x, t.v0.y, t.v0.z, t.v1.x, t.v1.y, t.v1.z,
+                t.v2.x, t.v2.y, t.v2.z, t.materialId);
     for (const Light &l : s.lights) {
-        if (l.type == AREA_LIGHT) fprintf(f, "light %u %.9g %.9g %.9g\n", l.primId, l.intensity.r, l.intensity.g, l.intensity.b);
+        if (l.type == AREA_LIGHT && l.primId >= s.primitives.size())
+            fprintf(f, "trianglelight %u %.9g %.9g %.9g\n", l.primId - (uint32_t)s.primitives.size(), l.intensity.r, l.intensity.g, l.intensity.b);
+        else if (l.type == AREA_LIGHT) fprintf(f, "light %u %.9g %.9g %.9g\n", l.primId, l.intensity.r, l.intensity.g, l.intensity.b);
         else fprintf(f, "pointlight %.9g %.9g %.9g %.9g %.9g %.9g\n", l.pos.x, l.pos.y, l.pos.z, l.intensity.r, l.intensity.g, l.intensity.b);
     }
 }

@@ -159,7 +159,7 @@ int main(int argc, char **argv)
         try {
             Camera camera(sd.eye, sd.look_at, sd.up, width, height, 0.f, 0.f, sd.fov);
             const MultiGpuResult r = RenderMultiGpu(camera, bounces, seed, sd.materials, sd.primitives, sd.lights, accel,
-                                                    gpus, split, iterations, batch, inject_failure);
+                                                    gpus, split, iterations, batch, inject_failure, sd.triangles);
             if (!r.ok) { fprintf(stderr, "ERROR: %s\n", r.error.c_str()); return 1; }
             printf("Pathtracer (%.4f sps : %u) on %u GPU(s), %s split, %.3f G bounces/s\n", iterations / r.seconds, iterations,
                    gpus, split == SplitMode::Tile ? "tile" : "sample", (double)r.rays / r.seconds / 1e9);
@@ -177,7 +177,7 @@ int main(int argc, char **argv)
     try {
         Camera camera(sd.eye, sd.look_at, sd.up, width, height, 0.f, 0.f, sd.fov);
         Pathtracer pathtracer(&camera, bounces, seed);
-        if (!pathtracer.Init(sd.materials, sd.primitives, sd.lights)) {
+        if (!pathtracer.Init(sd.materials, sd.primitives, sd.triangles, sd.lights)) {
             fprintf(stderr, "ERROR: Could not initialize Pathtracer: %s\n", pathtracer.LastError());
             return 1;
         }

@@ -69,6 +69,47 @@ def test_scene_file_round_trip(exe, tmp_path):
     assert run(exe, "--scene", path, "--dump-scene").stdout == text
 
 
+def test_scene_file_with_triangles_round_trips(exe, pt, tmp_path):
+    """Triangles (this build's extension) in the text format: statements in any order come back
+    spheres first, and a triangle's light names primitive <spheres> + <triangle> to the library."""
+    from triangle_scenes import box_room, scene_file_text
+    mats, sph, tris, lights, camera = box_room(pt)
+    text = scene_file_text(mats, sph, tris, lights, camera)
+    path = tmp_path / "room.scene"
+    path.write_text(text)
+    once = run(exe, "--scene", path, "--dump-scene").stdout
+    assert sum(l.startswith("triangle ") for l in once.splitlines()) == len(tris)
+    assert "trianglelight 12 12 12 12" in once and "trianglelight 13 12 12 12" in once
+    # triangle statements ahead of the spheres: the same scene
+    lines = text.splitlines()
+    shuffled = [lines[0]] + [l for l in lines if l.startswith("material")] + [l for l in lines if l.startswith("tri")] \
+        + [l for l in lines if l.startswith("sphere")]
+    path.write_text("\n".join(shuffled) + "\n")
+    assert run(exe, "--scene", path, "--dump-scene").stdout == once
+    path.write_text(once)
+    assert run(exe, "--scene", path, "--dump-scene").stdout == once
+
+
+@pytest.mark.gpu
+def test_cli_triangle_scene_renders_like_the_python_mirror(exe, pt, tmp_path):
+    import torch
+    from triangle_scenes import box_room, scene_file_text
+    mats, sph, tris, lights, camera = box_room(pt)
+    scene = tmp_path / "room.scene"
+    scene.write_text(scene_file_text(mats, sph, tris, lights, camera))
+    out = tmp_path / "room.pfm"
+    run(exe, "--scene", scene, "--width", 96, "--height", 64, "--depth", 6, "--seed", 5, "--iterations", 3, "--out", out)
+    eye, look, up, fov = camera
+    tr = pt.Pathtracer(pt.Camera(eye, look, up, 96, 64, 0, 0, fov), 6, 5)
+    tr.Init(mats, sph, lights, tris)
+    buf = torch.zeros(96 * 64 * 3, dtype=torch.float32, device="cuda")
+    tr.RunN(buf, 3)
+    torch.cuda.synchronize()
+    assert read_pfm(out).tobytes() == buf.cpu().numpy().tobytes()
+    assert float(buf.max()) > 0.0
+    tr.Release()
+
+
 @pytest.mark.parametrize("body,needle", [
     ("material diffuse 1 1 1\nsphere 0 0 0 1 1\n", "line 2: sphere refers to material 1"),
     ("material shiny 1 1 1\n", "line 1: unknown material type 'shiny'"),
@@ -78,8 +119,12 @@ def test_scene_file_round_trip(exe, tmp_path):
     ("material diffuse 1 1 1\nsphere 0 0 0 1 0 extra\n", "line 2: sphere needs"),
     ("material diffuse 1 nan 1\n", "line 1: material needs"),
     ("camera 0 0 0 0 0 1 0 1 0 190\n", "line 1: fov must be"),
-    ("triangle 0 0 0\n", "line 1: unknown statement 'triangle'"),
-    ("material diffuse 1 1 1\n", "the scene has no sphere"),
+    ("quad 0 0 0\n", "line 1: unknown statement 'quad'"),
+    ("material diffuse 1 1 1\ntriangle 0 0 0 1 0 0 0 1\n", "line 2: triangle needs"),
+    ("material diffuse 1 1 1\ntriangle 0 0 0 1 0 0 0 1 0 2\n", "line 2: triangle refers to material 2"),
+    ("material diffuse 1 1 1\ntriangle 0 0 0 1 0 0 0 1 0 0\ntrianglelight 1 1 1 1\n", "line 3: trianglelight refers to triangle 1"),
+    ("material diffuse 1 1 1\ntriangle 0 0 0 1 0 0 0 1 0 0\ntrianglelight 0 1 1 1\ntrianglelight 0 1 1 1\n", "line 4: triangle 0 already is a light"),
+    ("material diffuse 1 1 1\n", "the scene has no sphere and no triangle"),
 ])
 def test_scene_file_errors_name_the_line(exe, tmp_path, body, needle):
     path = tmp_path / "bad.scene"

@@ -84,3 +84,24 @@ def triangle_soup(pt, rng, n_tris, n_spheres):
     lights["u_bits"][0, 0] = 0 if n_spheres else min(6, n_tris - 1)
     lights["intensity"] = [[9, 8, 7]]
     return mats, sph, tris, lights, ([0, 45, 79.5], [0, 35, 0], [0, 1, 0], 55.0)
+
+
+def scene_file_text(mats, sph, tris, lights, camera):
+    """The scene in the headless front end's text format (host/scene_file.hpp); %.9g keeps every float bit."""
+    g = lambda v: " ".join("%.9g" % float(x) for x in np.atleast_1d(v))
+    eye, look, up, fov = camera
+    out = ["camera %s  %s  %s  %s" % (g(np.float32(eye)), g(np.float32(look)), g(np.float32(up)), g(np.float32(fov)))]
+    names = ["diffuse", "specular", "transmissive"]
+    out += ["material %s %s %s" % (names[int(m["type"])], g(m["color"]), g(m["coef"])) for m in mats]
+    out += ["sphere %s %s %d" % (g(s["pos"]), g(s["radius"]), int(s["material_id"])) for s in sph]
+    out += ["triangle %s  %s  %s  %d" % (g(t["v0"]), g(t["v1"]), g(t["v2"]), int(t["material_id"])) for t in tris]
+    # the text format gives every emitting primitive a light of its own; primitives that share one light
+    # here (a quad light's two triangles) come out as lights of equal intensity, which the trace loop
+    # cannot tell apart (it reads a light's intensity through the primitive that was hit, pathtracer.cu:133-137)
+    for k, p in enumerate(sph):
+        if p["light_id"] >= 0:
+            out.append("light %d %s" % (k, g(lights[int(p["light_id"])]["intensity"])))
+    for k, t in enumerate(tris):
+        if t["light_id"] >= 0:
+            out.append("trianglelight %d %s" % (k, g(lights[int(t["light_id"])]["intensity"])))
+    return "\n".join(out) + "\n"

@@ -42,6 +42,19 @@ static void scenes()
         CHECK(ParseScene(in, &b).empty());
         CHECK(dump(b) == text);
     }
+    {   // triangles: written after the spheres, lights renumbered to sphere count + triangle index both ways
+        const char *text = "camera 0 1 5 0 1 0 0 1 0 50\nmaterial diffuse 0.7 0.7 0.7\ntriangle 0 0 0 1 0 0 0 1 0 0\n"
+                           "trianglelight 0 4 4 4\nsphere 0 1 0 0.5 0\ntriangle 0 0 1 1 0 1 0 1 1 0\nlight 0 1 2 3\n";
+        std::istringstream in(text);
+        SceneDescription t, u;
+        CHECK(ParseScene(in, &t).empty());
+        CHECK(t.triangles.size() == 2 && t.primitives.size() == 1 && t.lights.size() == 2);
+        CHECK(t.lights[0].primId == 1 && t.triangles[0].lightId == 0 && t.lights[1].primId == 0);
+        const std::string once = dump(t);
+        std::istringstream again(once);
+        CHECK(ParseScene(again, &u).empty());
+        CHECK(dump(u) == once && u.lights[0].primId == 1);
+    }
     SceneDescription none;
     CHECK(!BuiltinScene(77, 1, &none));
     const char *bad[] = {
@@ -50,6 +63,10 @@ static void scenes()
         "material diffuse 1 1 1\nsphere 0 0 0 1 -1\n", "light 0 1 1 1\n", "camera 1 2 3\n", "camera 0 0 0 0 0 0 0 0 0 60\n",
         "pointlight 1 2\n", "material transmissive 1 1 1 inf\n", "\x01\x02\xff\xfe binary\n",
         "material diffuse 1 1 1\nsphere 0 0 0 1 0\nlight 0 1 1 1\nlight 0 1 1 1\n",
+        "material diffuse 1 1 1\ntriangle 0 0 0 1 0 0 0 1\n", "material diffuse 1 1 1\ntriangle 0 0 0 1 0 0 0 1 0 3\n",
+        "material diffuse 1 1 1\ntriangle 0 0 0 1 0 0 0 1 0 0\ntrianglelight 1 1 1 1\n",
+        "material diffuse 1 1 1\ntriangle 0 0 0 1 0 0 0 1 0 0\ntrianglelight 0 1 1 1\ntrianglelight 0 1 1 1\n",
+        "material diffuse 1 1 1\ntriangle 0 0 0 1 0 0 0 nan 0 0\n",
     };
     for (const char *t : bad) {
         SceneDescription s;

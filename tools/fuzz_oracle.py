@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised comparison of the shipped kernels with the CPU oracle (the restatement of the
 reference's trace loop): random small frames, depths, iteration counts and scenes (built-in ones
-and random sphere clouds of all three materials, through the linear scan or the BVH), both integrators,
+and random sphere clouds of all three materials, through the linear scan or the BVH; random triangle soups
+with and without spheres, resident or streamed through LDS tiles), both integrators,
 one call or a series of asynchronous calls; frame
 buffers and Intersect-call counts must agree bit for bit.
 
@@ -16,19 +17,25 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 pt = importlib.import_module("cuda-pathtracer_amd")
 import oracle_py as O  # noqa: E402
 from fuzz_steal import random_cloud  # noqa: E402
+from triangle_scenes import triangle_soup  # noqa: E402
 
 
 def one_case(seed):
     rng = np.random.default_rng(seed)
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5))
+    tris = None
     eye, look, up, fov = [0, 45, 79.5], [0, 35, 0], [0, 1, 0], 55.0
     if kind == 0:
         mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO, 1)
     elif kind == 1:
         mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_MIXED, 1)
+    elif kind == 4:
+        mats, sph, tris, lights, (eye, look, up, fov) = triangle_soup(
+            pt, rng, int(rng.choice([1, 9, 40, 256, 257, 700])), int(rng.choice([0, 0, 5, 30, 300])))
     else:
         mats, sph, lights = random_cloud(rng, int(rng.choice([3, 30, 150, 260, 600])))
         mats["coef"][2] = rng.choice([1.1, 1.5, 2.4])
@@ -40,12 +47,14 @@ def one_case(seed):
     # the direct-light integrator (the wavefront variant's per-bounce queues do not carry it), and the
     # render as a series of pt_run_async calls
     nee = variant != pt.VARIANT_WAVEFRONT and rng.random() < 0.4
+    if tris is not None:        # scenes with triangles: the path pool only
+        variant, accel, nee = pt.VARIANT_AUTO, pt.ACCEL_AUTO, False
     use_async = rng.random() < 0.3
     cam = pt.Camera(eye, look, up, w, h, 0, 0, fov)
     ref, _, _, ref_rays = O.oracle_render(cam.pod, mats, sph, lights, seed & 0xffff, depth, n_iterations=n, n_threads=16,
-                                          integrator=O.INTEGRATOR_NEE_MIS if nee else O.INTEGRATOR_PATH)
+                                          integrator=O.INTEGRATOR_NEE_MIS if nee else O.INTEGRATOR_PATH, triangles=tris)
     tr = pt.Pathtracer(cam, depth, seed & 0xffff)
-    tr.Init(mats, sph, lights)
+    tr.Init(mats, sph, lights, tris)
     tr.SetAccel(accel)
     tr.SetKernelVariant(variant)
     tr.SetIntegrator(pt.INTEGRATOR_NEE_MIS if nee else pt.INTEGRATOR_PATH)
