@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload demo1080|synth10k|mixed16]
+    python bench.py --gpus N --steps K --warmup W [--workload demo1080|demo4k|synth10k|mixed16|triroom1080]
 
 A "step" is one full render of the workload: every pixel's camera rays, nearest-hit scans,
 BSDF sampling and accumulation for all of the workload's iterations (one pt_run_n launch).
@@ -57,14 +57,29 @@ WORKLOADS = {
                      label="synthetic 10 007-sphere scene 1920x1080, 16 iterations of 4 paths per pixel, depth 8"),
     "mixed16": dict(scene="SCENE_MIXED", width=1920, height=1080, iterations=32, depth=16,
                     label="mixed diffuse/specular/glass grid 1920x1080, 32 iterations of 4 paths per pixel, depth 16"),
+    # this build's triangle extension (no counterpart in the reference, parity unpinned): the demo room with walls of triangles
+    "triroom1080": dict(scene="TRIANGLE_ROOM", width=1920, height=1080, iterations=64, depth=8,
+                        label="demo room built from 14 triangles + 3 spheres (extension: the reference has no triangles) "
+                              "1920x1080, 64 iterations of 4 paths per pixel, depth 8"),
 }
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (256 CU x 256 flop/clk x 2.4 GHz)
 
 
-def flops_per_ray(n_spheres: int) -> int:
+def flops_per_ray(n_spheres: int, n_triangles: int = 0) -> int:
     """Algorithmic flops of one Intersect call + one bounce of shading: 17 per sphere test
-    (3 sub, two 5-flop dots, b*b, -, r*r, +) + 21 for hit point/normal + 100 for the BSDF."""
-    return 17 * n_spheres + 121
+    (3 sub, two 5-flop dots, b*b, -, r*r, +) + 21 for hit point/normal + 100 for the BSDF.
+    A triangle test (Moeller-Trumbore, evaluated in full): two cross products of 9, four dot
+    products of 5, o - v0, 1/det and three products with it = 45."""
+    return 17 * n_spheres + 45 * n_triangles + 121
+
+
+def load_scene(pt, wl):
+    """(materials, spheres, triangles or None, lights, (eye, look_at, up, fov)) of a workload."""
+    if wl["scene"] == "TRIANGLE_ROOM":
+        mats, sph, tris, lights, cam = pt.triangle_room()
+        return mats, sph, tris, lights, cam
+    mats, sph, lights, cam = pt.build_scene(getattr(pt, wl["scene"]), 1)
+    return mats, sph, None, lights, cam
 
 
 def flops_per_ray_bvh(workload: str):
@@ -103,7 +118,7 @@ def host_description():
             "cores_share_of_this_gpu": share, "cores_used": used}
 
 
-def cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render=None):
+def cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render=None, tris=None):
     """Time the CPU oracle on a bounded sample of the same workload (about 10-30 s of CPU work).
     gpu_render(n_iterations) -> numpy image: when given, the oracle's rows are also compared with
     the GPU's image of the same iterations (image RMSE / max abs difference; expected 0)."""
@@ -114,7 +129,7 @@ def cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render=None):
     w, h = wl["width"], wl["height"]
     # ~15 s of CPU work: the oracle does about 5.4e6 Intersect calls/s/thread on 9 spheres
     # and scales with the number of sphere tests per call
-    rate = 5.4e6 * 24.0 / (len(sph) + 15.0)
+    rate = 5.4e6 * 24.0 / (len(sph) + (2.5 * len(tris) if tris is not None else 0) + 15.0)
     budget_rays = 15.0 * threads * rate
     rays_per_row = w * 4 * 3.7
     if budget_rays >= rays_per_row * h:
@@ -124,7 +139,7 @@ def cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render=None):
     y0 = (h - rows) // 2
     t0 = time.perf_counter()
     cpu_img, _, _, rays = O.oracle_render(cam.pod, mats, sph, lights, 1, wl["depth"], first_iteration=1,
-                                          n_iterations=iters, rect=(0, y0, w, y0 + rows), n_threads=threads)
+                                          n_iterations=iters, rect=(0, y0, w, y0 + rows), n_threads=threads, triangles=tris)
     dt = time.perf_counter() - t0
     out = {"value": rays / dt, "unit": "path-bounces/s", "cores": threads, "kind": "port",
            "sample": f"{wl['label']}: rows {y0}..{y0 + rows} x {iters} iteration(s), {rays} Intersect calls "
@@ -136,7 +151,7 @@ def cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render=None):
         out["image_vs_gpu"] = {"rmse": float(np.sqrt((diff ** 2).mean())), "max_abs": float(np.abs(diff).max()),
                                "pixels": int(rows * w), "iterations": int(iters),
                                "note": "GPU image vs this CPU image, same seed and iterations; parity is bit-exact"}
-    if O.have_ref():
+    if O.have_ref() and tris is None:
         # the reference's own trace logic compiled for host (oracle/_ref, prebuilt in the
         # development container), single-threaded as the reference is, on a smaller sample
         rows1 = max(1, min(h, int(5.0 * rate / rays_per_row)))
@@ -159,11 +174,11 @@ def measure_other_workload(pt, torch, name, accel, steps):
     """One more workload on this GPU, outside the headline's timed region: K steps between two
     events on the render stream after one untimed step.  Returns its line for `other_workloads`."""
     wl = WORKLOADS[name]
-    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(getattr(pt, wl["scene"]), 1)
+    mats, sph, tris, lights, (eye, look, up, fov) = load_scene(pt, wl)
     cam = pt.Camera(eye, look, up, wl["width"], wl["height"], 0.0, 0.0, fov)
     tr = pt.Pathtracer(cam, wl["depth"], seed=1)
     try:
-        tr.Init(mats, sph, lights)
+        tr.Init(mats, sph, lights, tris)
         tr.SetAccel(pt.ACCEL_AUTO if accel == "auto" else pt.ACCEL_BRUTE_FORCE)
         bvh = accel == "auto" and tr.AccelNodes() > 0
         tr.SetStream(torch.cuda.current_stream().cuda_stream)
@@ -179,7 +194,7 @@ def measure_other_workload(pt, torch, name, accel, steps):
         torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1) / steps
         rays = tr.RayCount() / steps
-        fpr = flops_per_ray_bvh(name) if bvh else flops_per_ray(len(sph))
+        fpr = flops_per_ray_bvh(name) if bvh else flops_per_ray(len(sph), 0 if tris is None else len(tris))
         achieved = rays * fpr / (ms * 1e-3) / 1e12 if fpr else None
         return {"workload": wl["label"], "nearest_hit": "sphere BVH" if bvh else "linear scan", "steps": steps,
                 "ms_per_step": ms, "value": rays / (ms * 1e-3), "unit": "path-bounces/s",
@@ -303,10 +318,10 @@ def main():
     pt = importlib.import_module("cuda-pathtracer_amd")
     sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
     wl = WORKLOADS[args.workload]
-    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(getattr(pt, wl["scene"]), 1)
+    mats, sph, tris, lights, (eye, look, up, fov) = load_scene(pt, wl)
     cam = pt.Camera(eye, look, up, wl["width"], wl["height"], 0.0, 0.0, fov)
     tr = pt.Pathtracer(cam, wl["depth"], seed=1)
-    tr.Init(mats, sph, lights)
+    tr.Init(mats, sph, lights, tris)
     tr.SetKernelVariant(args.variant)
     tr.SetAccel(pt.ACCEL_AUTO if args.accel == "auto" else pt.ACCEL_BRUTE_FORCE)
     tr.SetIntegrator(pt.INTEGRATOR_NEE_MIS if args.integrator == "nee" else pt.INTEGRATOR_PATH)
@@ -438,7 +453,7 @@ def main():
     # library's own event pair around the last launch is used instead.
     launch_ms = region_ms / args.steps if not grouped else grouped_launch_ms
     rays_per_launch = rays_local / max(1, args.steps)
-    fpr = flops_per_ray_bvh(args.workload) if bvh else flops_per_ray(len(sph))
+    fpr = flops_per_ray_bvh(args.workload) if bvh else flops_per_ray(len(sph), 0 if tris is None else len(tris))
     # HBM bytes per step from the committed PMC passes of this same command (rocprofv3 cannot be
     # run from inside the benchmark): profiles/pmc_traffic_<workload>_v<variant>.json
     launch = tr.LastLaunch()
@@ -473,6 +488,7 @@ def main():
             "build_id": build_id,
             "config": {"workload": wl["label"], "serial_launches": bool(args.serial_launches), "paths_per_step_per_gpu": wl["width"] * wl["height"] * 4 * n_it // (world if tile_split else 1),
                        "bounces_per_step_per_gpu": rays_per_launch, "spheres": int(len(sph)),
+                       "triangles": 0 if tris is None else int(len(tris)),
                        "parallelism": "single" if world == 1 else
                                       f"{'tile (16-row bands)' if tile_split else 'sample-range'} split x{world} + "
                                       f"{'RCCL' if backend == 'nccl' else backend + ' (rehearsal, staged through host memory)'} "
@@ -503,7 +519,7 @@ def main():
             # run of this file measures all of them (not part of `value`, outside its timed region).
             others = []
             for name, accel, k in (("mixed16", "auto", 5), ("synth10k", "auto", 4), ("synth10k", "brute", 3),
-                                   ("demo4k", "auto", 3)):
+                                   ("demo4k", "auto", 3), ("triroom1080", "auto", 3)):
                 try:
                     others.append(measure_other_workload(pt, torch, name, accel, k))
                 except Exception as e:   # the headline line must not depend on these
@@ -514,7 +530,7 @@ def main():
                 tr.Reset()
                 tr.RunN(buf, n, sync=True)
                 return buf.cpu().numpy().reshape(wl["height"], wl["width"], 3)
-            out["cpu_baseline"] = cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render)
+            out["cpu_baseline"] = cpu_baseline(pt, wl, mats, sph, lights, cam, gpu_render, tris)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -241,6 +241,46 @@ def build_scene(scene_id: int = SCENE_DEMO, seed: int = 1):
     return mats, sph, lights, (eye, look_at, up, float(fov.value))
 
 
+def triangle_room():
+    """The demo scene's room (main.cpp:153-161) with its walls made of triangles -- an extension: the
+    reference has spheres only (primitive.h:25-28).  Twelve wall triangles whose normals point INTO the room
+    (the trace loop never flips a normal, pathtracer.cu:130), a quad light of two triangles under the
+    ceiling facing down, the demo scene's mirror and glass spheres and a small diffuse one.
+    Returns (materials, spheres, triangles, lights, (eye, look_at, up, fov))."""
+    mats = np.zeros(6, MATERIAL_DTYPE)
+    mats["color"] = [[1, 1, 1], [.75, .25, .25], [.25, .25, .75], [.75, .75, .75], [.999, .999, .999], [.999, .999, .999]]
+    mats["type"] = [0, 0, 0, 0, 1, 2]
+    mats["coef"] = [0, 0, 0, 0, 1, 1.5]
+    x0, x1, y0, y1, z0, z1 = -50.0, 50.0, 0.0, 80.0, -80.0, 80.0
+
+    def quad(a, b, c, d, mat, light=-1):    # triangles a-c-b and a-d-c: the normal is (c - a) x (b - a)
+        t = np.zeros(2, TRIANGLE_DTYPE)
+        t["v0"], t["v1"], t["v2"] = [a, a], [c, d], [b, c]
+        t["material_id"], t["light_id"] = mat, light
+        return t
+
+    ly = y1 - 0.5
+    tris = np.concatenate([
+        quad((x1, y0, z0), (x1, y1, z0), (x1, y1, z1), (x1, y0, z1), 2),      # x = +50, normal -x
+        quad((x0, y0, z0), (x0, y0, z1), (x0, y1, z1), (x0, y1, z0), 1),      # x = -50, normal +x
+        quad((x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (x1, y0, z0), 3),      # back, normal +z
+        quad((x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1), 3),      # front, normal -z
+        quad((x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1), 3),      # floor, normal +y
+        quad((x0, y1, z0), (x0, y1, z1), (x1, y1, z1), (x1, y1, z0), 3),      # ceiling, normal -y
+        quad((-15, ly, -55), (-15, ly, -25), (15, ly, -25), (15, ly, -55), 0, 0),   # light, normal -y
+    ])
+    sph = np.zeros(3, SPHERE_DTYPE)
+    sph["pos"] = [[-25, 16.5, -50], [25, 16.5, -25], [0, 6, -10]]
+    sph["radius"] = [16.5, 16.5, 6]
+    sph["material_id"] = [4, 5, 1]
+    sph["light_id"] = -1
+    lights = np.zeros(1, LIGHT_DTYPE)
+    lights["type"] = AREA_LIGHT
+    lights["u_bits"][0, 0] = len(sph) + 12          # the light's first triangle
+    lights["intensity"] = [[12, 12, 12]]
+    return mats, sph, tris, lights, (np.float32([0, 45, 79.5]), np.float32([0, 35, 0]), np.float32([0, 1, 0]), 60.0)
+
+
 def debug_plan_batches(width, height, n_iterations, bytes_per_path, memory_limit=0, bands=None):
     """(rows owned, iterations per batch, buffer sets, slots per sub-queue) -- the host-side batch
     planner of the path pool / wavefront variant; bands = (band_rows, rank, world).  No device needed."""

@@ -4,49 +4,9 @@ pt_light."""
 import numpy as np
 
 
-def _tri(pt, v0, v1, v2, mat, light=-1):
-    t = np.zeros(1, pt.TRIANGLE_DTYPE)
-    t["v0"], t["v1"], t["v2"] = v0, v1, v2
-    t["material_id"], t["light_id"] = mat, light
-    return t
-
-
-def _quad(pt, a, b, c, d, mat, light=-1):
-    """Two triangles a-c-b, a-d-c; the normal is (c - a) x (b - a)."""
-    return [_tri(pt, a, c, b, mat, light), _tri(pt, a, d, c, mat, light)]
-
-
 def box_room(pt):
-    """The demo scene's room (main.cpp:153-161) with walls made of triangles whose normals point INTO
-    the room (the trace loop never flips a normal, pathtracer.cu:130), a quad light under the ceiling
-    facing down, and the demo scene's mirror and glass spheres plus a small diffuse one.
-    Returns (materials, spheres, triangles, lights, camera tuple)."""
-    mats = np.zeros(6, pt.MATERIAL_DTYPE)
-    mats["color"] = [[1, 1, 1], [.75, .25, .25], [.25, .25, .75], [.75, .75, .75], [.999, .999, .999], [.999, .999, .999]]
-    mats["type"] = [0, 0, 0, 0, 1, 2]
-    mats["coef"] = [0, 0, 0, 0, 1, 1.5]
-    x0, x1, y0, y1, z0, z1 = -50.0, 50.0, 0.0, 80.0, -80.0, 80.0
-    P = lambda x, y, z: np.array([x, y, z], np.float32)
-    tris = []
-    tris += _quad(pt, P(x1, y0, z0), P(x1, y1, z0), P(x1, y1, z1), P(x1, y0, z1), 2)   # x = +50, normal -x
-    tris += _quad(pt, P(x0, y0, z0), P(x0, y0, z1), P(x0, y1, z1), P(x0, y1, z0), 1)   # x = -50, normal +x
-    tris += _quad(pt, P(x0, y0, z0), P(x0, y1, z0), P(x1, y1, z0), P(x1, y0, z0), 3)   # back z = -80, normal +z
-    tris += _quad(pt, P(x0, y0, z1), P(x1, y0, z1), P(x1, y1, z1), P(x0, y1, z1), 3)   # front z = +80, normal -z
-    tris += _quad(pt, P(x0, y0, z0), P(x1, y0, z0), P(x1, y0, z1), P(x0, y0, z1), 3)   # floor, normal +y
-    tris += _quad(pt, P(x0, y1, z0), P(x0, y1, z1), P(x1, y1, z1), P(x1, y1, z0), 3)   # ceiling, normal -y
-    ly = y1 - 0.5
-    tris += _quad(pt, P(-15, ly, -55), P(-15, ly, -25), P(15, ly, -25), P(15, ly, -55), 0, 0)   # light, normal -y
-    tris = np.concatenate(tris)
-    sph = np.zeros(3, pt.SPHERE_DTYPE)
-    sph["pos"] = [[-25, 16.5, -50], [25, 16.5, -25], [0, 6, -10]]
-    sph["radius"] = [16.5, 16.5, 6]
-    sph["material_id"] = [4, 5, 1]
-    sph["light_id"] = -1
-    lights = np.zeros(1, pt.LIGHT_DTYPE)
-    lights["type"] = 1
-    lights["u_bits"][0, 0] = len(sph) + 12          # the light's first triangle
-    lights["intensity"] = [[12, 12, 12]]
-    return mats, sph, tris, lights, ([0, 45, 79.5], [0, 35, 0], [0, 1, 0], 60.0)
+    """The package's room of triangles: (materials, spheres, triangles, lights, camera tuple)."""
+    return pt.triangle_room()
 
 
 def triangle_soup(pt, rng, n_tris, n_spheres):

@@ -14,6 +14,7 @@ $B --workload mixed16 > $O/r3_bench_mixed16.json 2>> $O/r3_bench.err || exit 1
 $B --workload synth10k > $O/r3_bench_synth10k.json 2>> $O/r3_bench.err || exit 1
 $B --workload synth10k --accel brute --steps 3 > $O/r3_bench_synth10k_brute.json 2>> $O/r3_bench.err || exit 1
 $B --workload demo4k --no-cpu-baseline > $O/r3_bench_demo4k.json 2>> $O/r3_bench.err || exit 1
+$B --workload triroom1080 > $O/r3_bench_triroom1080.json 2>> $O/r3_bench.err || exit 1
 $B --variant 500 --no-cpu-baseline > $O/r3_bench_demo1080_stealing.json 2>> $O/r3_bench.err || exit 1
 $B --integrator nee --no-cpu-baseline > $O/r3_bench_demo1080_nee.json 2>> $O/r3_bench.err || exit 1
 $B --integrator nee --workload mixed16 --no-cpu-baseline > $O/r3_bench_mixed16_nee.json 2>> $O/r3_bench.err || exit 1
