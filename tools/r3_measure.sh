@@ -2,12 +2,20 @@
 # Runs ON THE GPU BOX: the round's measurements in one call -- profiles (kernel traces + counter passes) of
 # the three default launch structures, bench lines of every workload, the multi-rank rehearsals that one
 # GPU allows, and the launch-granularity table.  Results under gpurun_out/.
+#   tools/r3_measure.sh [all|profiles|bench]
+# The bench lines quote the counters of profiles/pmc_traffic_*.json only when those were taken from the very
+# build of the library that runs (its build id): after a rebuild run "profiles", condense the result in
+# the development container (tools/r3_collect.sh), then run "bench".
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out
+WHAT=${1:-all}
+if [ "$WHAT" != bench ]; then
 bash tools/profile_box.sh r3_demo1080_pool --steps 5 --warmup 1 > $O/r3_prof_demo.log 2>&1 || { tail -3 $O/r3_prof_demo.log; exit 1; }
 bash tools/profile_box.sh r3_synth10k_bvh --workload synth10k --steps 3 --warmup 1 > $O/r3_prof_synth.log 2>&1 || { tail -3 $O/r3_prof_synth.log; exit 1; }
 bash tools/profile_box.sh r3_mixed16_pool --workload mixed16 --steps 3 --warmup 1 > $O/r3_prof_mixed.log 2>&1 || { tail -3 $O/r3_prof_mixed.log; exit 1; }
+fi
+[ "$WHAT" = profiles ] && { echo "r3 profiles done"; exit 0; }
 B="timeout -k 10 300 python bench.py --no-other-workloads"
 $B > $O/r3_bench_demo1080.json 2> $O/r3_bench.err || exit 1
 $B --workload mixed16 > $O/r3_bench_mixed16.json 2>> $O/r3_bench.err || exit 1
