@@ -22,6 +22,9 @@ namespace {
 
 // Waves per SIMD the registers of the direct-light kernels are allocated for (measured choices).
 #ifndef PT_NEE_BVH_WAVES
+#ifndef PT_BVH_WAVES
+#define PT_BVH_WAVES 6   // waves per SIMD of the path integrator's wf_step_bvh_kernel
+#endif
 #define PT_NEE_BVH_WAVES 5   // waves per SIMD of the direct-light variant of wf_step_bvh_kernel
 #endif
 #ifndef PT_NEE_SHADOW_PASS_WAVES
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_step_kernel(const WavefrontP
 // is its path ray or, in the pass after a diffuse vertex parked a direct-light term, the shadow ray
 // of that vertex (`rd`, bounded by the distance to a point light).
 template <bool WHOLE, bool NEE = false>
-__global__ __launch_bounds__(kBlockThreads, NEE ? PT_NEE_BVH_WAVES : 6) void wf_step_bvh_kernel(const WavefrontParams p)
+__global__ __launch_bounds__(kBlockThreads, NEE ? PT_NEE_BVH_WAVES : PT_BVH_WAVES) void wf_step_bvh_kernel(const WavefrontParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int BT = kBlockThreads;
@@ -742,7 +745,7 @@ hipError_t launch_wavefront_step(const WavefrontParams &p, bool tiled, hipStream
         // run as a second round behind the first and wait for it.
         const int n_cus = current_device_cus();
         uint32_t per_cu = (uint32_t)((160u * 1024u) / (lds ? lds : 1));
-        const uint32_t by_registers = (p.whole_paths && p.nee) ? PT_NEE_BVH_WAVES : 6u;
+        const uint32_t by_registers = (p.whole_paths && p.nee) ? PT_NEE_BVH_WAVES : (uint32_t)PT_BVH_WAVES;
         if (per_cu > by_registers) per_cu = by_registers;
         if (per_cu < 1u) per_cu = 1u;
         uint32_t rows = (per_cu * (uint32_t)n_cus + kWfSubQueues - 1) / kWfSubQueues;
