@@ -111,3 +111,48 @@ def test_what_triangles_do_not_support_is_refused(pt, torch_cuda):
     tr.Reset()
     tr.RunN(buf, 1)
     tr.Release()
+
+
+def test_triangle_walls_converge_to_the_sphere_walled_demo_scene(pt, torch_cuda):
+    """Validation by convergence (the triangle code has nothing in the reference to be pinned to): the demo
+    scene's walls are spheres of radius 1e5 (main.cpp:153-161), flat to 0.03 units over the room.  The same
+    room with its six walls made of triangles in the same planes -- everything else kept: mirror and glass
+    sphere, the light sphere -- is the same scene physically, so both renders converge to one image; the
+    sphere-walled one is pinned to the reference bit for bit.  The difference between the two must be of
+    the size of the difference between two sphere-walled renders with different seeds, and shrink like it.
+    (Measured: 0.248 against a seed-to-seed 0.250 at 256 paths per pixel, 0.073 against 0.060 at 4096; what
+    remains beyond the noise is the sphere walls' own fp32 roughness -- the discriminant of a radius-1e5
+    sphere cancels numbers of size 1e10 -- which flat walls do not have.)"""
+    mats, sph, lights, (eye, look, up, fov) = pt.build_scene(pt.SCENE_DEMO, 1)
+    _, _, room_tris, _, _ = pt.triangle_room()
+    walls = room_tris[:12].copy()                     # the room's six walls, same planes and materials as spheres 0..5
+    assert [int(m) for m in walls["material_id"][::2]] == [int(m) for m in sph["material_id"][:6]]
+    inner = sph[6:].copy()                            # mirror sphere, glass sphere, light sphere
+    tri_lights = lights.copy()
+    tri_lights["u_bits"][0, 0] = 2                    # the light sphere is primitive 2 now
+    w, h, depth = 48, 36, 8
+    cam = pt.Camera(eye, look, up, w, h, 0, 0, fov)
+
+    def render(seed, n, triangles):
+        tr = pt.Pathtracer(cam, depth, seed)
+        if triangles:
+            tr.Init(mats, inner, tri_lights, walls)
+        else:
+            tr.Init(mats, sph, lights)
+        buf = torch_cuda.zeros(w * h * 3, dtype=torch_cuda.float32, device="cuda")
+        tr.RunN(buf, n)
+        torch_cuda.cuda.synchronize()
+        img = buf.cpu().numpy().reshape(h, w, 3).astype(np.float64)
+        tr.Release()
+        return img
+
+    def rmse(a, b):
+        return float(np.sqrt(((a - b) ** 2).mean()))
+
+    noise, diff = {}, {}
+    for n in (64, 1024):
+        a, b, t = render(11, n, False), render(12, n, False), render(13, n, True)
+        noise[n], diff[n] = rmse(a, b), rmse(a, t)
+        assert abs(t.mean() / a.mean() - 1.0) < 0.02, (n, t.mean(), a.mean())        # same energy in the frame
+    assert diff[64] < 1.25 * noise[64] and diff[1024] < 1.5 * noise[1024], (noise, diff)
+    assert diff[1024] < 0.4 * diff[64], (noise, diff)                                  # ~1/4 for 16x the samples
